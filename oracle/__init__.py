@@ -1,0 +1,1 @@
+"""Parity oracle (test infrastructure only; never imported by the product package)."""
