@@ -1,0 +1,177 @@
+/*
+ * librwr -- MI355X-native Random-Walk-with-Restart engine, C-ABI boundary.
+ *
+ * This header is the drop-in boundary for the public surface of the reference's
+ * namespace Recommenders.RWRBased (ChangUk/RecommenderSystems).  The reference is
+ * 100 % managed C# with no FFI of its own; a thin C# shim (INTEGRATION.md,
+ * csharp/Recommenders/RWRBased/) keeps the reference's public types and P/Invokes
+ * exactly the entry points declared here.  Every entry point cites the reference
+ * interface it replaces as file:line relative to the reference root.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch types cross this boundary;
+ *   - every function returns an int32 status (RWR_OK == 0); rwr_last_error() returns a
+ *     thread-local UTF-8 message for the last failing call on the calling thread
+ *     (the shim turns statuses into the .NET exceptions the reference would throw);
+ *   - all pointers are HOST pointers unless a parameter says otherwise;
+ *   - handles are independent: distinct rwr_graph handles may be used concurrently from
+ *     distinct host threads (the reference runs up to 10 worker threads, each with its
+ *     own Graph/Recommender: Program.cs:11,61-66; Experiment.cs:71,104,108).  One handle
+ *     must not be used from two threads at once;
+ *   - there is NO CPU fallback: every compute entry point fails with RWR_E_NO_DEVICE
+ *     when no gfx950 device is usable.
+ */
+#ifndef RWR_H
+#define RWR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RWR_VERSION_STRING "0.1.0"
+
+/* status codes */
+enum {
+    RWR_OK            = 0,
+    RWR_E_INVALID     = 1,   /* bad argument (null pointer, negative size, malformed CSR)        */
+    RWR_E_RANGE       = 2,   /* node index out of range  -> ArgumentOutOfRangeException/KeyNotFound */
+    RWR_E_NO_DEVICE   = 3,   /* no usable HIP device                                             */
+    RWR_E_HIP         = 4,   /* a HIP runtime call failed (message has the HIP error string)     */
+    RWR_E_NOMEM       = 5,   /* host or device allocation failed                                 */
+    RWR_E_CAPACITY    = 6,   /* caller's output buffer too small (needed size returned)          */
+    RWR_E_UNSUPPORTED = 7    /* valid request this build does not implement                      */
+};
+
+/* enum NodeType { UNDEFINED, USER, ITEM, ETC }                     -- Recommender.cs:4 */
+enum { RWR_NODE_UNDEFINED = 0, RWR_NODE_USER = 1, RWR_NODE_ITEM = 2, RWR_NODE_ETC = 3 };
+/* enum EdgeType { UNDEFINED, LIKE, FRIENDSHIP, FOLLOW, MENTION, AUTHORSHIP, PURCHASE, ETC }
+ *                                                                  -- Recommender.cs:5 */
+enum { RWR_EDGE_UNDEFINED = 0, RWR_EDGE_LIKE = 1, RWR_EDGE_FRIENDSHIP = 2, RWR_EDGE_FOLLOW = 3,
+       RWR_EDGE_MENTION = 4, RWR_EDGE_AUTHORSHIP = 5, RWR_EDGE_PURCHASE = 6, RWR_EDGE_ETC = 7 };
+
+/* arithmetic mode of the power iteration */
+enum {
+    RWR_MODE_EXACT = 0,  /* every rank value is bitwise what Model.deliverRanks (Model.cs:76-100)
+                            computes: same addends, same order, no FMA contraction              */
+    RWR_MODE_FAST  = 1   /* the seed's own row gathers its restart mass by a tree reduction
+                            (re-associated); every other row is still summed in reference order.
+                            Scores within 1e-6 of EXACT; rankings identical except across
+                            score gaps below ~1e-12 relative                                      */
+};
+
+/* rwr_model_run stop rule -- Model.run(int) / run(double) / run(): Model.cs:68-73,57-66,52-55 */
+enum { RWR_RUN_ITERATIONS = 0, RWR_RUN_THRESHOLD = 1, RWR_RUN_DEFAULT_THRESHOLD = 2 };
+
+typedef struct rwr_graph rwr_graph;   /* opaque: device-resident graph + workspaces + streams */
+
+typedef struct rwr_opts {
+    int32_t struct_size;     /* = sizeof(rwr_opts); lets the struct grow compatibly            */
+    int32_t device;          /* HIP device ordinal; -1 = env RWR_DEVICE, else current device   */
+    int32_t mode;            /* RWR_MODE_*; -1 = env RWR_MODE ("exact"/"fast"), else EXACT      */
+    int32_t tile_seeds;      /* seeds per rank-matrix tile (lanes per row): 1,2,4,8,16,32,64;
+                                0 = auto                                                        */
+    int32_t tile_group;      /* tiles iterated together (grid.y of the SpMM launch); 0 = auto  */
+    int32_t profile;         /* 1 = bracket every kernel phase with HIP events (rwr_get_stats)  */
+    int64_t workspace_bytes; /* cap on the batch workspace (rank matrices + sort buffers);
+                                0 = auto (a fraction of free HBM)                               */
+} rwr_opts;
+
+/* accumulated since creation or the last rwr_reset_stats(); *_ms are device times measured
+ * with HIP events on the library's own streams (only when opts.profile != 0) */
+typedef struct rwr_stats {
+    int32_t struct_size;
+    int32_t n;               /* nodes                                                           */
+    int64_t nnz_raw;         /* links handed over (incl. UNDEFINED)                             */
+    int64_t nnz;             /* explicit links (type != UNDEFINED) = entries of P               */
+    int32_t uniform;         /* 1 when every row's explicit raw weights are equal               */
+    int32_t tile_seeds;      /* resolved seeds per tile of the last batch                       */
+    int32_t tile_group;      /* resolved tiles per launch of the last batch                     */
+    int32_t mode;
+    double  build_ms;        /* device-side Graph.buildGraph + transpose (one-off)              */
+    double  spmm_ms;         /* sum of SpMM launch durations                                    */
+    int64_t spmm_launches;
+    int64_t spmm_seed_steps; /* sum over launches of (seeds in the launch) -- one unit = one
+                                power-iteration step of one seed                                */
+    double  chain_ms;        /* exact-mode seed-row kernel / fast-mode restart reduction        */
+    int64_t chain_launches;
+    double  rank_ms;         /* exclusion mask + top-k / sort + gather                          */
+    double  iterate_wall_ms; /* host wall time of the iterate phase (stream-synchronised)       */
+    double  total_wall_ms;   /* host wall time inside rwr_recommend* calls                      */
+    int64_t seeds_done;
+} rwr_stats;
+
+/* ---- library ------------------------------------------------------------------------- */
+
+const char *rwr_version(void);
+/* number of usable gfx950 devices (0 when none); never fails */
+int32_t rwr_device_count(void);
+/* message of the last failure on this thread ("" if none) */
+const char *rwr_last_error(void);
+
+/* ---- Graph ---------------------------------------------------------------------------
+ * Replaces  new Graph(nodes, edges) + Graph.buildGraph()   (Graph.cs:45-49, 51-88; called
+ * at Experiment.cs:104-105) and Graph.size() (Graph.cs:91-93).
+ *
+ * Input is the RAW link list exactly as the host built it, flattened in dictionary/list
+ * order:  node i (0..n-1, the keys of Dictionary<int,Node>, Graph.cs:39) has
+ * id node_id[i] / type node_type[i] (struct Node, Graph.cs:4-17) and out-links
+ * rowptr[i]..rowptr[i+1]-1, each (dst, etype, w) = struct ForwardLink
+ * {targetNode, type, weight} (Graph.cs:19-35) in List<ForwardLink> order
+ * (Graph.cs:40).  Links are NOT filtered or normalised by the caller: the library drops
+ * type == UNDEFINED links, sums the remaining weights of a source left to right and
+ * divides (Graph.cs:57-81) on the device, then builds the in-neighbour (transposed) CSR
+ * with entries ordered (source asc, list position asc) -- the addend order of
+ * Model.deliverRanks.  A node without explicit links is dangling (Graph.cs:53,64,86).
+ * A key missing from the edge dictionary is passed as an empty list.
+ * The arrays are copied; the caller may free them after the call returns. */
+int32_t rwr_graph_create(int32_t n, const int64_t *node_id, const uint8_t *node_type,
+                         const int64_t *rowptr /* n+1 */, const int32_t *dst, const uint8_t *etype,
+                         const double *w, const rwr_opts *opts /* may be NULL */, rwr_graph **out);
+int32_t rwr_graph_destroy(rwr_graph *g);
+/* Graph.size() (Graph.cs:91-93) plus link counts; any out pointer may be NULL */
+int32_t rwr_graph_size(const rwr_graph *g, int32_t *n, int64_t *nnz_raw, int64_t *nnz_explicit);
+/* Backs the public field Graph.graph (Graph.cs:43): w_out[e] = normalised weight of raw
+ * link e (0 for UNDEFINED links, which the reference leaves out of graph[i]);
+ * dangling_out[i] = 1 when graph[i] == null.  Either pointer may be NULL. */
+int32_t rwr_graph_get_normalized(rwr_graph *g, double *w_out /* nnz_raw */, uint8_t *dangling_out /* n */);
+
+/* ---- Recommender ---------------------------------------------------------------------
+ * Replaces Recommender.Recommendation(int idxTargetUser, float dampingFactor, int nIteration)
+ * (Recommender.cs:14-40) and the topN overload (Recommender.cs:42-51):
+ *   personalised Model (Model.cs:33-50), run(nIteration) (Model.cs:68-73), exclusion of the
+ *   seed's raw LIKE out-links (Recommender.cs:20-24), candidates = ITEM nodes not excluded
+ *   (:27-31), sorted by score desc then id desc (:35-38).
+ * d crosses as float and is widened natively, as Recommender.cs:16 -> Model.cs:33 does.
+ * top_n <= 0 returns the whole list (the reference's Count == topN test never fires).
+ * in:  *inout_count = capacity of out_id/out_score;  out: entries written.  If the list
+ * needs more room the call fails with RWR_E_CAPACITY and *inout_count = required size
+ * (n always suffices). */
+int32_t rwr_recommend(rwr_graph *g, int32_t seed, float d, int32_t n_iter, int32_t top_n,
+                      int64_t *out_id, double *out_score, int64_t *inout_count);
+
+/* Batch entry (an addition: the reference creates a fresh Model per call, Recommender.cs:16,
+ * so seeds are independent and batching is semantically free).  top_n must be >= 1.
+ * ids/scores are K x top_n row-major; counts[k] = entries valid in row k (the rest of the
+ * row is id 0 / score 0).  Result k is exactly rwr_recommend(seeds[k], d, n_iter, top_n). */
+int32_t rwr_recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, float d, int32_t n_iter,
+                            int32_t top_n, int64_t *ids, double *scores, int32_t *counts);
+
+/* ---- Model ---------------------------------------------------------------------------
+ * Backs the public class Model: ctor (Model.cs:33-50 personalised, seed >= 0;
+ * Model.cs:14-31 global, seed == -1), run(int) / run(double) / run() (Model.cs:68-73,
+ * 57-66, 52-55 incl. checkConvergence :110-115).  d is already a double here
+ * (Model.cs:33 takes double).  rank_out receives Model.rank (n doubles) after the run;
+ * iters_out (optional) the number of deliverRanks() calls made. */
+int32_t rwr_model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double value,
+                      double *rank_out, int64_t *iters_out);
+
+/* ---- measurement ---------------------------------------------------------------------- */
+int32_t rwr_get_stats(rwr_graph *g, rwr_stats *out);
+int32_t rwr_reset_stats(rwr_graph *g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RWR_H */

@@ -1,0 +1,259 @@
+// C-ABI entry points of librwr (include/rwr.h).  No CPU fallback anywhere: without a
+// usable gfx950 device every compute entry fails with RWR_E_NO_DEVICE.
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "engine.h"
+
+namespace rwr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static int usable_devices()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+static int32_t bind_device(const rwr_graph *g)
+{
+    RWR_HIP(hipSetDevice(g->device));
+    return RWR_OK;
+}
+
+}  // namespace rwr
+
+using namespace rwr;
+
+extern "C" {
+
+const char *rwr_version(void) { return RWR_VERSION_STRING " (gfx950, hip)"; }
+
+int32_t rwr_device_count(void) { return usable_devices(); }
+
+const char *rwr_last_error(void) { return g_err; }
+
+int32_t rwr_graph_create(int32_t n, const int64_t *node_id, const uint8_t *node_type, const int64_t *rowptr,
+                         const int32_t *dst, const uint8_t *etype, const double *w, const rwr_opts *opts,
+                         rwr_graph **out)
+{
+    g_err[0] = 0;
+    if (!out) { set_error("rwr_graph_create: out is NULL"); return RWR_E_INVALID; }
+    *out = nullptr;
+    if (n <= 0 || !node_id || !node_type || !rowptr) {
+        set_error("rwr_graph_create: n must be > 0 and node_id/node_type/rowptr non-NULL");
+        return RWR_E_INVALID;
+    }
+    if (rowptr[0] != 0) { set_error("rwr_graph_create: rowptr[0] must be 0"); return RWR_E_INVALID; }
+    for (int32_t i = 0; i < n; ++i)
+        if (rowptr[i + 1] < rowptr[i]) {
+            set_error("rwr_graph_create: rowptr decreases at node %d", i);
+            return RWR_E_INVALID;
+        }
+    const int64_t m = rowptr[n];
+    if (m > 0 && (!dst || !etype || !w)) {
+        set_error("rwr_graph_create: dst/etype/w must be non-NULL when there are links");
+        return RWR_E_INVALID;
+    }
+    const int ndev = usable_devices();
+    if (ndev <= 0) { set_error("no usable HIP device (librwr has no CPU fallback)"); return RWR_E_NO_DEVICE; }
+
+    rwr_graph *g = new (std::nothrow) rwr_graph();
+    if (!g) { set_error("out of host memory"); return RWR_E_NOMEM; }
+    rwr_opts o{};
+    o.struct_size = sizeof(rwr_opts);
+    o.device = -1;
+    o.mode = -1;
+    if (opts) {
+        size_t sz = opts->struct_size > 0 ? (size_t)opts->struct_size : sizeof(rwr_opts);
+        if (sz > sizeof(rwr_opts)) sz = sizeof(rwr_opts);
+        memcpy(&o, opts, sz);
+    }
+    if (o.device < 0) {
+        const char *e = getenv("RWR_DEVICE");
+        if (e && *e) o.device = atoi(e);
+        else {
+            int cur = 0;
+            if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+            o.device = cur;
+        }
+    }
+    if (o.mode < 0) {
+        const char *e = getenv("RWR_MODE");
+        o.mode = (e && strcmp(e, "fast") == 0) ? RWR_MODE_FAST : RWR_MODE_EXACT;
+    }
+    if (o.device >= ndev) {
+        set_error("rwr_graph_create: device %d requested but only %d visible", o.device, ndev);
+        delete g;
+        return RWR_E_NO_DEVICE;
+    }
+    if (o.mode != RWR_MODE_EXACT && o.mode != RWR_MODE_FAST) {
+        set_error("rwr_graph_create: unknown mode %d", o.mode);
+        delete g;
+        return RWR_E_INVALID;
+    }
+    g->opts = o;
+    g->device = o.device;
+    g->n = n;
+    g->nnz_raw = m;
+    int32_t rc = RWR_OK;
+    auto fail = [&](int32_t code) {
+        rwr_graph_destroy(g);
+        return code;
+    };
+    if (hipSetDevice(g->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", g->device); return fail(RWR_E_HIP); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, g->device) != hipSuccess) { set_error("hipGetDeviceProperties failed"); return fail(RWR_E_HIP); }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; librwr is built for gfx950 only", g->device, prop.gcnArchName);
+        return fail(RWR_E_NO_DEVICE);
+    }
+    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&g->ev_a) != hipSuccess || hipEventCreate(&g->ev_b) != hipSuccess) {
+        set_error("stream/event creation failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail(RWR_E_HIP);
+    }
+    rc = graph_build(g, node_id, node_type, rowptr, dst, etype, w);
+    if (rc != RWR_OK) return fail(rc);
+    g->stats.struct_size = sizeof(rwr_stats);
+    g->stats.n = n;
+    g->stats.nnz_raw = m;
+    g->stats.nnz = g->nnz;
+    g->stats.uniform = g->uniform;
+    g->stats.mode = g->opts.mode;
+    *out = g;
+    return RWR_OK;
+}
+
+int32_t rwr_graph_destroy(rwr_graph *g)
+{
+    if (!g) return RWR_OK;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->stream2) (void)hipStreamSynchronize(g->stream2);
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
+    if (g->ev_a) (void)hipEventDestroy(g->ev_a);
+    if (g->ev_b) (void)hipEventDestroy(g->ev_b);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    if (g->stream2) (void)hipStreamDestroy(g->stream2);
+    delete g;
+    return RWR_OK;
+}
+
+int32_t rwr_graph_size(const rwr_graph *g, int32_t *n, int64_t *nnz_raw, int64_t *nnz_explicit)
+{
+    if (!g) { set_error("rwr_graph_size: graph is NULL"); return RWR_E_INVALID; }
+    if (n) *n = g->n;
+    if (nnz_raw) *nnz_raw = g->nnz_raw;
+    if (nnz_explicit) *nnz_explicit = g->nnz;
+    return RWR_OK;
+}
+
+int32_t rwr_graph_get_normalized(rwr_graph *g, double *w_out, uint8_t *dangling_out)
+{
+    g_err[0] = 0;
+    if (!g) { set_error("rwr_graph_get_normalized: graph is NULL"); return RWR_E_INVALID; }
+    RWR_TRY(bind_device(g));
+    if (w_out && g->nnz_raw > 0)
+        RWR_HIP(hipMemcpy(w_out, g->w_norm_raw.p, sizeof(double) * (size_t)g->nnz_raw, hipMemcpyDeviceToHost));
+    if (dangling_out) RWR_HIP(hipMemcpy(dangling_out, g->dangling.p, (size_t)g->n, hipMemcpyDeviceToHost));
+    return RWR_OK;
+}
+
+int32_t rwr_recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, float d, int32_t n_iter, int32_t top_n,
+                            int64_t *ids, double *scores, int32_t *counts)
+{
+    g_err[0] = 0;
+    if (!g || !seeds || !ids || !scores || !counts) { set_error("rwr_recommend_batch: NULL argument"); return RWR_E_INVALID; }
+    if (K <= 0) { set_error("rwr_recommend_batch: K must be >= 1"); return RWR_E_INVALID; }
+    if (top_n < 1) { set_error("rwr_recommend_batch: top_n must be >= 1"); return RWR_E_INVALID; }
+    if (n_iter < 0) n_iter = 0;   // Model.run(int): a non-positive count runs no iteration (Model.cs:69)
+    RWR_TRY(bind_device(g));
+    // Recommender.cs:14,16 -> Model.cs:33: the float is widened to double
+    return recommend_batch(g, seeds, K, (double)d, n_iter, top_n, ids, scores, counts, top_n);
+}
+
+int32_t rwr_recommend(rwr_graph *g, int32_t seed, float d, int32_t n_iter, int32_t top_n, int64_t *out_id,
+                      double *out_score, int64_t *inout_count)
+{
+    g_err[0] = 0;
+    if (!g || !inout_count) { set_error("rwr_recommend: NULL argument"); return RWR_E_INVALID; }
+    if (seed < 0 || seed >= g->n) { set_error("seed %d is outside [0, %d)", seed, g->n); return RWR_E_RANGE; }
+    if (n_iter < 0) n_iter = 0;
+    RWR_TRY(bind_device(g));
+    // Recommender.cs:42-51: topN <= 0 never truncates
+    int64_t width = (top_n > 0 && top_n < g->n_items) ? top_n : g->n_items;
+    if (width == 0) { *inout_count = 0; return RWR_OK; }
+    if (width > 0x7FFFFFFF) { set_error("rwr_recommend: list too long"); return RWR_E_UNSUPPORTED; }
+    std::vector<int64_t> hid((size_t)width);
+    std::vector<double> hsc((size_t)width);
+    int32_t cnt = 0;
+    RWR_TRY(recommend_batch(g, &seed, 1, (double)d, n_iter, (int32_t)width, hid.data(), hsc.data(), &cnt, width));
+    if (*inout_count < cnt || ((!out_id || !out_score) && cnt > 0)) {
+        set_error("rwr_recommend: output holds %lld entries, %d needed", (long long)*inout_count, cnt);
+        *inout_count = cnt;
+        return RWR_E_CAPACITY;
+    }
+    if (cnt > 0) {
+        memcpy(out_id, hid.data(), sizeof(int64_t) * (size_t)cnt);
+        memcpy(out_score, hsc.data(), sizeof(double) * (size_t)cnt);
+    }
+    *inout_count = cnt;
+    return RWR_OK;
+}
+
+int32_t rwr_model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double value, double *rank_out,
+                      int64_t *iters_out)
+{
+    g_err[0] = 0;
+    if (!g || !rank_out) { set_error("rwr_model_run: NULL argument"); return RWR_E_INVALID; }
+    RWR_TRY(bind_device(g));
+    if (seed == -1 || run_mode != RWR_RUN_ITERATIONS) {
+        set_error("rwr_model_run: the global model (seed -1) and threshold runs are not implemented yet");
+        return RWR_E_UNSUPPORTED;
+    }
+    int64_t T = (int64_t)value;
+    if (T < 0) T = 0;
+    RWR_TRY(model_run_iters(g, seed, d, T, rank_out));
+    if (iters_out) *iters_out = T;
+    return RWR_OK;
+}
+
+int32_t rwr_get_stats(rwr_graph *g, rwr_stats *out)
+{
+    if (!g || !out) { set_error("rwr_get_stats: NULL argument"); return RWR_E_INVALID; }
+    size_t sz = out->struct_size > 0 ? (size_t)out->struct_size : sizeof(rwr_stats);
+    if (sz > sizeof(rwr_stats)) sz = sizeof(rwr_stats);
+    rwr_stats s = g->stats;
+    s.struct_size = (int32_t)sz;
+    memcpy(out, &s, sz);
+    return RWR_OK;
+}
+
+int32_t rwr_reset_stats(rwr_graph *g)
+{
+    if (!g) { set_error("rwr_reset_stats: NULL argument"); return RWR_E_INVALID; }
+    rwr_stats &s = g->stats;
+    s.spmm_ms = s.chain_ms = s.rank_ms = s.iterate_wall_ms = s.total_wall_ms = 0;
+    s.spmm_launches = s.spmm_seed_steps = s.chain_launches = s.seeds_done = 0;
+    return RWR_OK;
+}
+
+}  // extern "C"

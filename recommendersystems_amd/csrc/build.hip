@@ -1,0 +1,224 @@
+// Device-side Graph.buildGraph (Graph.cs:51-88) + stable transpose into the in-neighbour CSR.
+//
+// Reference semantics reproduced exactly:
+//   * links with type == UNDEFINED are dropped from the walk          (Graph.cs:59,72)
+//   * sumWeights accumulates the explicit weights LEFT TO RIGHT       (Graph.cs:70-76)
+//   * each explicit weight is divided by that sum (IEEE fp64 divide)  (Graph.cs:80-81)
+//   * a node with no explicit link is dangling (graph[i] == null)     (Graph.cs:53,64,86)
+// The transpose is a STABLE sort of the raw link list by target: the raw list is in
+// (source asc, list position asc) order, so every in-neighbour list comes out in exactly
+// the order in which Model.deliverRanks adds into nextRank[target] (Model.cs:78,85-88).
+#include "engine.h"
+
+namespace rwr {
+
+// one thread per source row; sequential within the row (the sum order is part of the contract)
+__global__ __launch_bounds__(256) void k_row_prepare(
+    int32_t n, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ dst,
+    const uint8_t *__restrict__ etype, const double *__restrict__ w, double *__restrict__ w_norm,
+    int32_t *__restrict__ esrc, uint32_t *__restrict__ skey, uint32_t *__restrict__ sval,
+    uint8_t *__restrict__ dangling, double *__restrict__ w_src, int *__restrict__ flags)
+{
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t b = rowptr[i], e = rowptr[i + 1];
+    double sum = 0.0;
+    int64_t n_explicit = 0;
+    bool uni = true, bad = false;
+    double first = 0.0;
+    for (int64_t p = b; p < e; ++p) {
+        int32_t t = dst[p];
+        if (t < 0 || t >= n) bad = true;
+        if (etype[p] != RWR_EDGE_UNDEFINED) {
+            double wp = w[p];
+            if (n_explicit == 0) first = wp;
+            else if (wp != first) uni = false;
+            sum += wp;                                   // Graph.cs:75, list order
+            ++n_explicit;
+        }
+    }
+    for (int64_t p = b; p < e; ++p) {
+        bool ex = etype[p] != RWR_EDGE_UNDEFINED;
+        w_norm[p] = ex ? w[p] / sum : 0.0;               // Graph.cs:81
+        esrc[p] = i;
+        int32_t t = dst[p];
+        skey[p] = (ex && t >= 0 && t < n) ? (uint32_t)t : (uint32_t)n;   // UNDEFINED -> sentinel row n
+        sval[p] = (uint32_t)p;
+    }
+    dangling[i] = (n_explicit == 0) ? 1 : 0;             // Graph.cs:64,86
+    w_src[i] = (n_explicit > 0) ? first / sum : 0.0;
+    if (!uni) atomicOr(&flags[0], 1);
+    if (bad) atomicOr(&flags[1], 1);
+}
+
+// in_ptr[j] = first sorted position whose key >= j   (keys sorted ascending, sentinel n last)
+__global__ __launch_bounds__(256) void k_in_ptr(const uint32_t *__restrict__ skey, int64_t m, int32_t n,
+                                                int64_t *__restrict__ in_ptr)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > m) return;
+    // boundary between position p-1 and p
+    int64_t lo = (p == 0) ? -1 : (int64_t)skey[p - 1];
+    int64_t hi = (p == m) ? (int64_t)n : (int64_t)skey[p];
+    for (int64_t j = lo + 1; j <= hi; ++j) in_ptr[j] = p;
+}
+
+__global__ __launch_bounds__(256) void k_gather_in(const uint32_t *__restrict__ sval, int64_t nnz,
+                                                   const int32_t *__restrict__ esrc,
+                                                   const double *__restrict__ w_norm,
+                                                   int32_t *__restrict__ in_src, double *__restrict__ in_w)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    uint32_t e = sval[p];
+    in_src[p] = esrc[e];
+    in_w[p] = w_norm[e];
+}
+
+__global__ __launch_bounds__(256) void k_order_keys(int32_t n, const int64_t *__restrict__ in_ptr,
+                                                    const uint8_t *__restrict__ node_type,
+                                                    const int64_t *__restrict__ node_id,
+                                                    uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval,
+                                                    uint64_t *__restrict__ ikey, uint32_t *__restrict__ ival,
+                                                    int *__restrict__ maxdeg)
+{
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t deg = (uint32_t)(in_ptr[i + 1] - in_ptr[i]);
+    dkey[i] = ~deg;            // ascending sort of ~deg == in-degree descending
+    dval[i] = (uint32_t)i;
+    // items by id descending: ascending sort of ~orderable(id); non-items last
+    ikey[i] = (node_type[i] == RWR_NODE_ITEM) ? ~i64_orderable(node_id[i]) : ~0ull;
+    ival[i] = (uint32_t)i;
+    atomicMax(maxdeg, (int)deg);
+}
+
+__global__ void k_u32_to_i32(const uint32_t *__restrict__ a, int32_t *__restrict__ b, int64_t m)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < m) b[p] = (int32_t)a[p];
+}
+
+static int bit_length(uint64_t v)
+{
+    int b = 0;
+    while (v) { ++b; v >>= 1; }
+    return b;
+}
+
+int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_type, const int64_t *rowptr,
+                    const int32_t *dst, const uint8_t *etype, const double *w)
+{
+    const int32_t n = g->n;
+    const int64_t m = g->nnz_raw;
+    hipStream_t s = g->stream;
+    if (m >= 0xFFFFFFFFll) {
+        set_error("rwr_graph_create: %lld links exceed this build's per-device limit of 2^32-2", (long long)m);
+        return RWR_E_UNSUPPORTED;
+    }
+    g->h_rowptr.assign(rowptr, rowptr + n + 1);
+    int32_t n_items = 0;
+    for (int32_t i = 0; i < n; ++i) n_items += (node_type[i] == RWR_NODE_ITEM);
+    g->n_items = n_items;
+
+    RWR_TRY(g->node_id.alloc(n));
+    RWR_TRY(g->node_type.alloc(n));
+    RWR_TRY(g->rowptr.alloc((size_t)n + 1));
+    RWR_TRY(g->dst.alloc(m));
+    RWR_TRY(g->etype.alloc(m));
+    RWR_TRY(g->w_norm_raw.alloc(m));
+    RWR_TRY(g->dangling.alloc(n));
+    RWR_TRY(g->w_src.alloc(n));
+    RWR_TRY(g->in_ptr.alloc((size_t)n + 1));
+    RWR_TRY(g->row_order.alloc(n));
+    RWR_TRY(g->item_order.alloc(n_items));
+
+    DevBuf<double> w_raw;
+    DevBuf<int32_t> esrc;
+    DevBuf<uint32_t> skey, skey2, sval, sval2;
+    DevBuf<uint8_t> temp;
+    DevBuf<int> flags;
+    RWR_TRY(w_raw.alloc(m));
+    RWR_TRY(esrc.alloc(m));
+    RWR_TRY(skey.alloc(m));
+    RWR_TRY(skey2.alloc(m));
+    RWR_TRY(sval.alloc(m));
+    RWR_TRY(sval2.alloc(m));
+    RWR_TRY(flags.alloc(4));
+    size_t tbytes = radix_sort_temp_bytes((size_t)m, 1);
+    size_t tb2 = radix_sort_temp_bytes((size_t)n, 1);
+    RWR_TRY(temp.alloc(tbytes > tb2 ? tbytes : tb2));
+
+    RWR_HIP(hipMemcpyAsync(g->node_id.p, node_id, sizeof(int64_t) * n, hipMemcpyHostToDevice, s));
+    RWR_HIP(hipMemcpyAsync(g->node_type.p, node_type, (size_t)n, hipMemcpyHostToDevice, s));
+    RWR_HIP(hipMemcpyAsync(g->rowptr.p, rowptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
+    if (m > 0) {
+        RWR_HIP(hipMemcpyAsync(g->dst.p, dst, sizeof(int32_t) * m, hipMemcpyHostToDevice, s));
+        RWR_HIP(hipMemcpyAsync(g->etype.p, etype, (size_t)m, hipMemcpyHostToDevice, s));
+        RWR_HIP(hipMemcpyAsync(w_raw.p, w, sizeof(double) * m, hipMemcpyHostToDevice, s));
+    }
+    int h_flags[4] = {0, 0, 0, 0};   // [0] some row non-uniform, [1] bad target, [2] max in-degree
+    RWR_HIP(hipMemsetAsync(flags.p, 0, sizeof(h_flags), s));
+
+    hipEvent_t e0 = g->ev_a, e1 = g->ev_b;
+    RWR_HIP(hipEventRecord(e0, s));
+
+    hipLaunchKernelGGL(k_row_prepare, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->rowptr.p, g->dst.p, g->etype.p,
+                       w_raw.p, g->w_norm_raw.p, esrc.p, skey.p, sval.p, g->dangling.p, g->w_src.p, flags.p);
+    RWR_HIP(hipGetLastError());
+
+    // stable sort of the raw links by target (UNDEFINED links carry the sentinel key n and go last)
+    bool alt = false;
+    RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)m, 1, bit_length((uint64_t)n),
+                                       temp.p, s, &alt));
+    uint32_t *k_sorted = alt ? skey2.p : skey.p;
+    uint32_t *v_sorted = alt ? sval2.p : sval.p;
+    hipLaunchKernelGGL(k_in_ptr, dim3(cdiv((size_t)m + 1, 256)), dim3(256), 0, s, k_sorted, m, n, g->in_ptr.p);
+    RWR_HIP(hipGetLastError());
+    int64_t nnz = 0;
+    RWR_HIP(hipMemcpyAsync(&nnz, g->in_ptr.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipStreamSynchronize(s));
+    if (h_flags[1]) {
+        set_error("rwr_graph_create: a link targets a node outside [0, %d)", n);
+        return RWR_E_RANGE;
+    }
+    g->nnz = nnz;
+    g->uniform = h_flags[0] ? 0 : 1;
+    RWR_TRY(g->in_src.alloc((size_t)nnz));
+    RWR_TRY(g->in_w.alloc((size_t)nnz));
+    if (nnz > 0) {
+        hipLaunchKernelGGL(k_gather_in, dim3(cdiv((size_t)nnz, 256)), dim3(256), 0, s, v_sorted, nnz, esrc.p,
+                           g->w_norm_raw.p, g->in_src.p, g->in_w.p);
+        RWR_HIP(hipGetLastError());
+    }
+
+    // destination-row processing order (in-degree descending) and ITEM rows by id descending
+    DevBuf<uint64_t> ikey, ikey2;
+    DevBuf<uint32_t> ival, ival2;
+    RWR_TRY(ikey.alloc(n));
+    RWR_TRY(ikey2.alloc(n));
+    RWR_TRY(ival.alloc(n));
+    RWR_TRY(ival2.alloc(n));
+    hipLaunchKernelGGL(k_order_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->in_ptr.p, g->node_type.p,
+                       g->node_id.p, skey.p, sval.p, ikey.p, ival.p, flags.p + 2);
+    RWR_HIP(hipGetLastError());
+    RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, 32, temp.p, s, &alt));
+    hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p, g->row_order.p,
+                       (int64_t)n);
+    RWR_TRY(radix_sort_pairs<uint64_t>(ikey.p, ikey2.p, ival.p, ival2.p, (size_t)n, 1, 64, temp.p, s, &alt));
+    if (n_items > 0)
+        hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n_items, 256)), dim3(256), 0, s, alt ? ival2.p : ival.p,
+                           g->item_order.p, (int64_t)n_items);
+    RWR_HIP(hipGetLastError());
+    RWR_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipEventRecord(e1, s));
+    RWR_HIP(hipStreamSynchronize(s));
+    g->max_in_deg = h_flags[2];
+    float ms = 0.f;
+    RWR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    g->stats.build_ms = ms;
+    return RWR_OK;
+}
+
+}  // namespace rwr

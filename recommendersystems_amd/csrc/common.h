@@ -1,0 +1,88 @@
+// librwr internal definitions (gfx950 only; built with -ffp-contract=off).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rwr.h"
+
+namespace rwr {
+
+void set_error(const char *fmt, ...);
+
+#define RWR_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            rwr::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,  \
+                           __LINE__);                                                         \
+            return (e__ == hipErrorOutOfMemory) ? RWR_E_NOMEM : RWR_E_HIP;                    \
+        }                                                                                     \
+    } while (0)
+
+#define RWR_TRY(call)                  \
+    do {                               \
+        int32_t s__ = (call);          \
+        if (s__ != RWR_OK) return s__; \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// order-preserving map of a non-NaN double to uint64 (ascending); -0.0 is first
+// canonicalised to +0.0 so that double.CompareTo's -0.0 == +0.0 holds for keys
+__host__ __device__ static inline uint64_t f64_orderable(double x)
+{
+    x = x + 0.0;
+    uint64_t u;
+    __builtin_memcpy(&u, &x, 8);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__host__ __device__ static inline uint64_t i64_orderable(int64_t x)
+{
+    return (uint64_t)x ^ 0x8000000000000000ull;
+}
+
+// ------------------------------------------------------------------ device buffers
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t count = 0;
+    int32_t alloc(size_t n_elems)
+    {
+        release();
+        if (n_elems == 0) n_elems = 1;
+        RWR_HIP(hipMalloc((void **)&p, n_elems * sizeof(T)));
+        count = n_elems;
+        return RWR_OK;
+    }
+    int32_t ensure(size_t n_elems)
+    {
+        if (p && count >= n_elems) return RWR_OK;
+        return alloc(n_elems);
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+// ------------------------------------------------------------------ radix sort (sort.hip)
+// Stable LSD radix sort of (key, u32 payload) pairs, nseg equal-length segments laid out
+// [seg][m].  Sorts key bits [0, key_bits).  Result lands in (keys, vals) or (keys_alt,
+// vals_alt); *in_alt tells which.  temp must hold radix_sort_temp_bytes(m, nseg).
+size_t radix_sort_temp_bytes(size_t m, int nseg);
+template <typename KeyT>
+int32_t radix_sort_pairs(KeyT *keys, KeyT *keys_alt, uint32_t *vals, uint32_t *vals_alt, size_t m,
+                         int nseg, int key_bits, void *temp, hipStream_t stream, bool *in_alt);
+
+}  // namespace rwr

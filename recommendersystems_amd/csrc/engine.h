@@ -1,0 +1,64 @@
+// Device-resident graph and batch workspace (internal).
+#pragma once
+#include "common.h"
+
+struct rwr_graph {
+    int32_t device = 0;
+    int32_t n = 0;
+    int64_t nnz_raw = 0;     // links handed over
+    int64_t nnz = 0;         // explicit links = entries of the transition matrix
+    int32_t n_items = 0;     // nodes of type ITEM
+    int32_t uniform = 0;     // every row's explicit raw weights equal
+    int32_t max_in_deg = 0;
+    rwr_opts opts{};
+
+    // node SoA (struct Node, Graph.cs:4-17)
+    rwr::DevBuf<int64_t> node_id;
+    rwr::DevBuf<uint8_t> node_type;
+    // raw out-links in list order (struct ForwardLink, Graph.cs:19-35); kept for the
+    // exclusion list, which reads the RAW list (Recommender.cs:20-24)
+    rwr::DevBuf<int64_t> rowptr;
+    rwr::DevBuf<int32_t> dst;
+    rwr::DevBuf<uint8_t> etype;
+    rwr::DevBuf<double> w_norm_raw;   // Graph.graph weights per raw link (0 for UNDEFINED)
+    std::vector<int64_t> h_rowptr;    // host copy (seed validation, exclusion sizing)
+    // transposed (in-neighbour) CSR of the normalised matrix, entries ordered
+    // (source asc, list position asc) = addend order of Model.deliverRanks
+    rwr::DevBuf<int64_t> in_ptr;
+    rwr::DevBuf<int32_t> in_src;
+    rwr::DevBuf<double> in_w;
+    rwr::DevBuf<double> w_src;        // uniform graphs: the one normalised weight of source i
+    rwr::DevBuf<uint8_t> dangling;    // graph[i] == null (Graph.cs:53,86)
+    rwr::DevBuf<int32_t> row_order;   // destination rows by in-degree descending (stable)
+    rwr::DevBuf<int32_t> item_order;  // ITEM rows by id descending
+
+    // batch workspace (lazily sized)
+    rwr::DevBuf<double> X, Y;         // rank matrices [tile][n][G]
+    rwr::DevBuf<int32_t> d_seeds;     // [tile][G], -1 = padding lane
+    rwr::DevBuf<double> d_part;       // fast mode: restart partial sums
+    rwr::DevBuf<uint64_t> keys, keys_alt;
+    rwr::DevBuf<uint32_t> vals, vals_alt;
+    rwr::DevBuf<uint8_t> sort_temp;
+    rwr::DevBuf<int64_t> d_out_id;
+    rwr::DevBuf<double> d_out_score;
+    rwr::DevBuf<int32_t> d_counts;
+
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;   // profiling pairs
+
+    rwr_stats stats{};
+};
+
+namespace rwr {
+
+int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_type, const int64_t *rowptr,
+                    const int32_t *dst, const uint8_t *etype, const double *w);
+
+// runs the power iteration for K seeds and leaves, per seed, the ranked list
+// (mode 0: top-k into host arrays; mode 1: full rank vector of one seed)
+int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d, int32_t n_iter, int32_t top_n,
+                        int64_t *ids, double *scores, int32_t *counts, int64_t row_stride);
+int32_t model_run_iters(rwr_graph *g, int32_t seed, double d, int64_t n_iter, double *rank_out);
+
+}  // namespace rwr

@@ -1,0 +1,472 @@
+// RWR power iteration  x <- (1-c) P^T x + c e   (Model.deliverRanks / updateRanks,
+// Model.cs:76-108) for a batch of seeds, on gfx950.
+//
+// Data layout: the rank matrix is kept seed-minor, tile by tile:  X[tile][node][G]
+// (G = seeds per tile = lanes per row, a power of two <= 64).  One lane owns one
+// (destination row, seed) pair and walks the row's in-neighbour list sequentially, so
+//   * every in-neighbour access of a lane group is one contiguous G*8-byte row of X
+//     (a full 128-byte line at G = 16): coalesced, no per-element gathers;
+//   * the addends arrive in exactly the reference's order (source asc, list position
+//     asc), so every row except the seed's own is BITWISE what the C# computes -- no
+//     reductions, no atomics (SURVEY.md section 3.3 point 1);
+//   * pull form writes every y[j] exactly once: updateRanks (Model.cs:103-108) is a
+//     pointer swap.
+// The seed's own row receives, besides its in-links, the restart mass of EVERY node
+// interleaved in node order (Model.cs:91-93,96-97): an n-term sequential fp64 chain per
+// seed.  EXACT mode reproduces that chain literally (k_seed_chain, one lane per seed, on a
+// second stream beside the SpMM); FAST mode sums the restart mass with a deterministic
+// tree (k_restart_partial/_final).
+//
+// Arithmetic per edge is the reference's:  rw = (1-d)*x_i  (Model.cs:84), then
+// nextRank += rw * weight (Model.cs:87) -- two roundings, never an FMA (the file is built
+// with -ffp-contract=off).
+#include "engine.h"
+
+#include <chrono>
+#include <climits>
+
+namespace rwr {
+
+template <int G>
+__global__ __launch_bounds__(256) void k_spmm(int32_t n, const int64_t *__restrict__ in_ptr,
+                                              const int32_t *__restrict__ in_src,
+                                              const double *__restrict__ in_w,
+                                              const int32_t *__restrict__ row_order,
+                                              const double *__restrict__ X, double *__restrict__ Y,
+                                              const int32_t *__restrict__ seeds, double c1, int skip_seed_row)
+{
+    constexpr int RPW = WAVE / G;   // destination rows per wave
+    constexpr int U = 4;            // gathers in flight per lane
+    const int tile = blockIdx.y;
+    const size_t toff = (size_t)tile * (size_t)n * G;
+    X += toff;
+    Y += toff;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int sub = lane / G, k = lane % G;
+    const int32_t my_seed = skip_seed_row ? seeds[tile * G + k] : -1;
+    const int wpb = blockDim.x / WAVE;
+    const int64_t nwaves = (int64_t)gridDim.x * wpb;
+    for (int64_t rb = ((int64_t)blockIdx.x * wpb + threadIdx.x / WAVE) * RPW; rb < n; rb += nwaves * RPW) {
+        const int64_t r = rb + sub;
+        int32_t j = -1;
+        int64_t p = 0, e = 0;
+        if (r < n) {
+            j = row_order[r];
+            p = in_ptr[j];
+            e = in_ptr[j + 1];
+        }
+        double acc = 0.0;
+        for (; p + U <= e; p += U) {
+            int32_t idx[U];
+            double wv[U], xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) idx[u] = in_src[p + u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) wv[u] = in_w[p + u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = X[(size_t)idx[u] * G + k];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                double rw = c1 * xv[u];          // Model.cs:84
+                acc += rw * wv[u];               // Model.cs:87
+            }
+        }
+        for (; p < e; ++p) {
+            double rw = c1 * X[(size_t)in_src[p] * G + k];
+            acc += rw * in_w[p];
+        }
+        if (j >= 0 && j != my_seed) Y[(size_t)j * G + k] = acc;
+    }
+}
+
+// EXACT mode: the seed's own row.  Model.cs:78-99 for target == seed: for i ascending,
+// first i's links into the seed (list order), then the restart addend
+// rank[i] - rw (non-dangling, Model.cs:91-93) or rank[i] (dangling, Model.cs:96-97).
+template <int G>
+__global__ __launch_bounds__(64) void k_seed_chain(int32_t n, int ntiles, const int64_t *__restrict__ in_ptr,
+                                                   const int32_t *__restrict__ in_src,
+                                                   const double *__restrict__ in_w,
+                                                   const uint8_t *__restrict__ dangling,
+                                                   const double *__restrict__ X, double *__restrict__ Y,
+                                                   const int32_t *__restrict__ seeds, double c1)
+{
+    constexpr int U = 8;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;   // (tile, k)
+    if (q >= ntiles * G) return;
+    const int tile = q / G, k = q % G;
+    const int32_t s = seeds[q];
+    if (s < 0) return;
+    const double *x = X + (size_t)tile * (size_t)n * G + k;
+    int64_t p = in_ptr[s];
+    const int64_t e = in_ptr[s + 1];
+    int32_t nxt = (p < e) ? in_src[p] : INT_MAX;
+    double acc = 0.0;
+    int32_t i = 0;
+    for (; i + U <= n; i += U) {
+        double xv[U];
+        uint8_t dg[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = x[(size_t)(i + u) * G];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dg[u] = dangling[i + u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double rw = c1 * xv[u];
+            while (nxt == i + u) {
+                acc += rw * in_w[p];
+                ++p;
+                nxt = (p < e) ? in_src[p] : INT_MAX;
+            }
+            acc += dg[u] ? xv[u] : (xv[u] - rw);
+        }
+    }
+    for (; i < n; ++i) {
+        double xi = x[(size_t)i * G];
+        double rw = c1 * xi;
+        while (nxt == i) {
+            acc += rw * in_w[p];
+            ++p;
+            nxt = (p < e) ? in_src[p] : INT_MAX;
+        }
+        acc += dangling[i] ? xi : (xi - rw);
+    }
+    Y[(size_t)tile * (size_t)n * G + (size_t)s * G + k] = acc;
+}
+
+// FAST mode: restart mass R_k = sum_i (dangling_i ? x_i : x_i - (1-d) x_i), deterministic tree.
+constexpr int RP_BLOCK = 256;
+template <int G>
+__global__ __launch_bounds__(RP_BLOCK) void k_restart_partial(int32_t n, const uint8_t *__restrict__ dangling,
+                                                              const double *__restrict__ X,
+                                                              double *__restrict__ part, double c1)
+{
+    constexpr int RL = RP_BLOCK / G;   // row lanes per block
+    __shared__ double sh[RP_BLOCK];
+    const int tile = blockIdx.y;
+    const double *x = X + (size_t)tile * (size_t)n * G;
+    const int k = threadIdx.x % G, rl = threadIdx.x / G;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * RL + rl; i < n; i += (int64_t)gridDim.x * RL) {
+        double xi = x[(size_t)i * G + k];
+        double rw = c1 * xi;
+        acc += dangling[i] ? xi : (xi - rw);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int half = RL / 2; half >= 1; half >>= 1) {
+        if (rl < half) sh[threadIdx.x] += sh[threadIdx.x + half * G];
+        __syncthreads();
+    }
+    if (rl == 0) part[((size_t)tile * gridDim.x + blockIdx.x) * G + k] = sh[k];
+}
+
+template <int G>
+__global__ void k_restart_final(int32_t n, int ntiles, int nblk, const double *__restrict__ part,
+                                double *__restrict__ Y, const int32_t *__restrict__ seeds)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ntiles * G) return;
+    const int tile = q / G, k = q % G;
+    const int32_t s = seeds[q];
+    if (s < 0) return;
+    double R = 0.0;
+    for (int b = 0; b < nblk; ++b) R += part[((size_t)tile * nblk + b) * G + k];
+    double *y = Y + (size_t)tile * (size_t)n * G + (size_t)s * G + k;
+    *y = *y + R;
+}
+
+// Model ctor, Model.cs:42-49: rank[seed] = nNodes, everything else 0
+__global__ void k_init_seeds(int32_t n, int ntiles, int G, double *__restrict__ X,
+                             const int32_t *__restrict__ seeds)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ntiles * G) return;
+    const int32_t s = seeds[q];
+    if (s < 0) return;
+    X[(size_t)(q / G) * (size_t)n * G + (size_t)s * G + (q % G)] = (double)n;
+}
+
+// Recommender.cs:20-24,29: the seed's RAW out-links of type LIKE are not candidates.
+// Marked by overwriting their (final) score with -1 -- valid scores are >= 0.
+__global__ void k_exclude(int32_t n, int ntiles, int G, const int64_t *__restrict__ rowptr,
+                          const int32_t *__restrict__ dst, const uint8_t *__restrict__ etype,
+                          double *__restrict__ X, const int32_t *__restrict__ seeds)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ntiles * G) return;
+    const int32_t s = seeds[q];
+    if (s < 0) return;
+    double *x = X + (size_t)(q / G) * (size_t)n * G + (q % G);
+    for (int64_t p = rowptr[s]; p < rowptr[s + 1]; ++p)
+        if (etype[p] == RWR_EDGE_LIKE) x[(size_t)dst[p] * G] = -1.0;
+}
+
+// ------------------------------------------------------------------------------ host side
+
+template <int G>
+static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
+                        int skip, hipStream_t s)
+{
+    constexpr int RPW = WAVE / G;
+    unsigned want = cdiv((size_t)g->n, (size_t)RPW * 4);
+    unsigned gx = want < 8192u ? want : 8192u;
+    hipLaunchKernelGGL(k_spmm<G>, dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p, g->in_w.p,
+                       g->row_order.p, X, Y, seeds, c1, skip);
+}
+template <int G>
+static void launch_chain(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
+                         hipStream_t s)
+{
+    hipLaunchKernelGGL(k_seed_chain<G>, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, g->n, tg, g->in_ptr.p,
+                       g->in_src.p, g->in_w.p, g->dangling.p, X, Y, seeds, c1);
+}
+constexpr int RP_GRID = 512;
+template <int G>
+static void launch_restart_partial(rwr_graph *g, int tg, const double *X, double c1, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_restart_partial<G>, dim3(RP_GRID, tg), dim3(RP_BLOCK), 0, s, g->n, g->dangling.p, X,
+                       g->d_part.p, c1);
+}
+template <int G>
+static void launch_restart_final(rwr_graph *g, int tg, double *Y, const int32_t *seeds, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_restart_final<G>, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, g->n, tg, RP_GRID,
+                       g->d_part.p, Y, seeds);
+}
+
+#define RWR_DISPATCH_G(G, CALL)                 \
+    switch (G) {                                \
+        case 1: { constexpr int GG = 1; CALL; } break;   \
+        case 2: { constexpr int GG = 2; CALL; } break;   \
+        case 4: { constexpr int GG = 4; CALL; } break;   \
+        case 8: { constexpr int GG = 8; CALL; } break;   \
+        case 16: { constexpr int GG = 16; CALL; } break; \
+        case 32: { constexpr int GG = 32; CALL; } break; \
+        default: { constexpr int GG = 64; CALL; } break; \
+    }
+
+struct EvPool {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    hipEvent_t get()
+    {
+        if (used == ev.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            ev.push_back(e);
+        }
+        return ev[used++];
+    }
+    ~EvPool()
+    {
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+};
+
+// declared in rank.hip
+int32_t rank_tile(rwr_graph *g, int G, int tile_in_group, int64_t first_seed_slot, int32_t n_real, int32_t top_n,
+                  const double *X, const int32_t *d_seeds_tile, hipStream_t s);
+
+static int resolve_G(const rwr_graph *g, int32_t K)
+{
+    int G = g->opts.tile_seeds;
+    if (G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64) return G;
+    int want = 1;
+    while (want < K && want < 16) want <<= 1;
+    return want;
+}
+
+int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, double d, int64_t n_iter,
+                      double **final_X, EvPool &pool, std::vector<hipEvent_t> &spmm_ev,
+                      std::vector<hipEvent_t> &chain_ev)
+{
+    const int32_t n = g->n;
+    const double c1 = 1 - d;   // Model.cs:84: (1 - dampingFactor)
+    hipStream_t s = g->stream, s2 = g->stream2;
+    const bool exact = g->opts.mode != RWR_MODE_FAST;
+    const bool prof = g->opts.profile != 0;
+    double *X = g->X.p, *Y = g->Y.p;
+    const size_t elems = (size_t)tg * (size_t)n * G;
+    RWR_HIP(hipMemsetAsync(X, 0, elems * sizeof(double), s));
+    hipLaunchKernelGGL(k_init_seeds, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, X, d_seeds);
+    for (int64_t it = 0; it < n_iter; ++it) {
+        if (exact) {
+            // fork: the seed-row chain runs beside the SpMM on the second stream
+            RWR_HIP(hipEventRecord(g->ev_fork, s));
+            RWR_HIP(hipStreamWaitEvent(s2, g->ev_fork, 0));
+            hipEvent_t c0 = nullptr, c1e = nullptr;
+            if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, s2)); }
+            RWR_DISPATCH_G(G, launch_chain<GG>(g, tg, X, Y, d_seeds, c1, s2));
+            if (prof) { RWR_HIP(hipEventRecord(c1e, s2)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
+            RWR_HIP(hipEventRecord(g->ev_join, s2));
+        } else {
+            hipEvent_t c0 = nullptr, c1e = nullptr;
+            if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, s)); }
+            RWR_DISPATCH_G(G, launch_restart_partial<GG>(g, tg, X, c1, s));
+            if (prof) { RWR_HIP(hipEventRecord(c1e, s)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
+        }
+        hipEvent_t a = nullptr, b = nullptr;
+        if (prof) { a = pool.get(); b = pool.get(); RWR_HIP(hipEventRecord(a, s)); }
+        RWR_DISPATCH_G(G, launch_spmm<GG>(g, tg, X, Y, d_seeds, c1, exact ? 1 : 0, s));
+        if (prof) { RWR_HIP(hipEventRecord(b, s)); spmm_ev.push_back(a); spmm_ev.push_back(b); }
+        if (exact) {
+            RWR_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
+        } else {
+            RWR_DISPATCH_G(G, launch_restart_final<GG>(g, tg, Y, d_seeds, s));
+        }
+        RWR_HIP(hipGetLastError());
+        double *t = X; X = Y; Y = t;   // Model.updateRanks (Model.cs:103-108)
+        g->stats.spmm_launches += 1;
+        g->stats.chain_launches += 1;
+    }
+    *final_X = X;
+    return RWR_OK;
+}
+
+static int32_t ensure_workspace(rwr_graph *g, int G, int32_t K, int *TG_out)
+{
+    const size_t n = (size_t)g->n;
+    const int ntiles = (int)cdiv((size_t)K, (size_t)G);
+    size_t cap = (size_t)g->opts.workspace_bytes;
+    if (cap == 0) {
+        size_t fr = 0, tot = 0;
+        RWR_HIP(hipMemGetInfo(&fr, &tot));
+        // what is already held by X/Y counts as available
+        fr += (g->X.count + g->Y.count) * sizeof(double);
+        cap = fr / 2;
+    }
+    const size_t per_tile = 2 * n * (size_t)G * sizeof(double);
+    int TG = g->opts.tile_group > 0 ? g->opts.tile_group : (int)(cap / (per_tile ? per_tile : 1));
+    if (TG < 1) TG = 1;
+    if (TG > ntiles) TG = ntiles;
+    if (TG > 65535) TG = 65535;
+    RWR_TRY(g->X.ensure((size_t)TG * n * G));
+    RWR_TRY(g->Y.ensure((size_t)TG * n * G));
+    RWR_TRY(g->d_seeds.ensure((size_t)ntiles * G));
+    RWR_TRY(g->d_part.ensure((size_t)TG * RP_GRID * G));
+    *TG_out = TG;
+    return RWR_OK;
+}
+
+static double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+static int32_t drain_events(std::vector<hipEvent_t> &v, double *acc)
+{
+    for (size_t i = 0; i + 1 < v.size(); i += 2) {
+        float ms = 0.f;
+        RWR_HIP(hipEventElapsedTime(&ms, v[i], v[i + 1]));
+        *acc += ms;
+    }
+    v.clear();
+    return RWR_OK;
+}
+
+int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d, int32_t n_iter, int32_t top_n,
+                        int64_t *ids, double *scores, int32_t *counts, int64_t row_stride)
+{
+    const double t_begin = now_ms();
+    const int32_t n = g->n;
+    for (int32_t k = 0; k < K; ++k)
+        if (seeds[k] < 0 || seeds[k] >= n) {
+            set_error("seed %d (batch position %d) is outside [0, %d)", seeds[k], k, n);
+            return RWR_E_RANGE;
+        }
+    const int G = resolve_G(g, K);
+    int TG = 1;
+    RWR_TRY(ensure_workspace(g, G, K, &TG));
+    const int ntiles = (int)cdiv((size_t)K, (size_t)G);
+    hipStream_t s = g->stream;
+    std::vector<int32_t> hs((size_t)ntiles * G, -1);
+    for (int32_t k = 0; k < K; ++k) hs[k] = seeds[k];
+    RWR_HIP(hipMemcpy(g->d_seeds.p, hs.data(), hs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    const size_t out_elems = (size_t)ntiles * G * (size_t)top_n;
+    RWR_TRY(g->d_out_id.ensure(out_elems));
+    RWR_TRY(g->d_out_score.ensure(out_elems));
+    RWR_TRY(g->d_counts.ensure((size_t)ntiles * G));
+    RWR_HIP(hipMemsetAsync(g->d_out_id.p, 0, out_elems * sizeof(int64_t), s));
+    RWR_HIP(hipMemsetAsync(g->d_out_score.p, 0, out_elems * sizeof(double), s));
+    RWR_HIP(hipMemsetAsync(g->d_counts.p, 0, (size_t)ntiles * G * sizeof(int32_t), s));
+
+    EvPool pool;
+    std::vector<hipEvent_t> spmm_ev, chain_ev, rank_ev;
+    const bool prof = g->opts.profile != 0;
+    double iter_wall = 0.0;
+    for (int t0 = 0; t0 < ntiles; t0 += TG) {
+        const int tg = (ntiles - t0 < TG) ? (ntiles - t0) : TG;
+        const int32_t *dseeds = g->d_seeds.p + (size_t)t0 * G;
+        double *Xf = nullptr;
+        double w0 = 0;
+        if (prof) { RWR_HIP(hipStreamSynchronize(s)); w0 = now_ms(); }
+        RWR_TRY(iterate_group(g, G, tg, dseeds, d, n_iter, &Xf, pool, spmm_ev, chain_ev));
+        if (prof) { RWR_HIP(hipStreamSynchronize(s)); iter_wall += now_ms() - w0; }
+        int32_t real = K - t0 * G;
+        if (real > tg * G) real = tg * G;
+        g->stats.spmm_seed_steps += (int64_t)real * n_iter;
+        hipEvent_t a = nullptr, b = nullptr;
+        if (prof) { a = pool.get(); b = pool.get(); RWR_HIP(hipEventRecord(a, s)); }
+        hipLaunchKernelGGL(k_exclude, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, g->rowptr.p,
+                           g->dst.p, g->etype.p, Xf, dseeds);
+        RWR_HIP(hipGetLastError());
+        for (int t = 0; t < tg; ++t) {
+            int32_t n_real = K - (t0 + t) * G;
+            if (n_real > G) n_real = G;
+            RWR_TRY(rank_tile(g, G, t, (int64_t)(t0 + t) * G, n_real, top_n, Xf + (size_t)t * (size_t)n * G,
+                              dseeds + (size_t)t * G, s));
+        }
+        if (prof) { RWR_HIP(hipEventRecord(b, s)); rank_ev.push_back(a); rank_ev.push_back(b); }
+    }
+    // results: K x top_n (device rows are top_n wide; host rows are row_stride wide)
+    std::vector<int32_t> hc((size_t)ntiles * G);
+    RWR_HIP(hipMemcpyAsync(hc.data(), g->d_counts.p, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipMemcpy2DAsync(ids, (size_t)row_stride * sizeof(int64_t), g->d_out_id.p, (size_t)top_n * sizeof(int64_t),
+                             (size_t)top_n * sizeof(int64_t), (size_t)K, hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipMemcpy2DAsync(scores, (size_t)row_stride * sizeof(double), g->d_out_score.p,
+                             (size_t)top_n * sizeof(double), (size_t)top_n * sizeof(double), (size_t)K,
+                             hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipStreamSynchronize(s));
+    RWR_HIP(hipStreamSynchronize(g->stream2));
+    for (int32_t k = 0; k < K; ++k) counts[k] = hc[k];
+    if (prof) {
+        RWR_TRY(drain_events(spmm_ev, &g->stats.spmm_ms));
+        RWR_TRY(drain_events(chain_ev, &g->stats.chain_ms));
+        RWR_TRY(drain_events(rank_ev, &g->stats.rank_ms));
+        g->stats.iterate_wall_ms += iter_wall;
+    }
+    g->stats.tile_seeds = G;
+    g->stats.tile_group = TG;
+    g->stats.seeds_done += K;
+    g->stats.total_wall_ms += now_ms() - t_begin;
+    return RWR_OK;
+}
+
+int32_t model_run_iters(rwr_graph *g, int32_t seed, double d, int64_t n_iter, double *rank_out)
+{
+    const int32_t n = g->n;
+    if (seed < 0 || seed >= n) {
+        set_error("seed %d is outside [0, %d)", seed, n);
+        return RWR_E_RANGE;
+    }
+    // one seed, one lane per row: the rank vector is contiguous
+    const int G = 1;
+    int TG = 1;
+    RWR_TRY(ensure_workspace(g, G, 1, &TG));
+    RWR_HIP(hipMemcpy(g->d_seeds.p, &seed, sizeof(int32_t), hipMemcpyHostToDevice));
+    EvPool pool;
+    std::vector<hipEvent_t> a, b;
+    double *Xf = nullptr;
+    RWR_TRY(iterate_group(g, G, 1, g->d_seeds.p, d, n_iter, &Xf, pool, a, b));
+    RWR_HIP(hipMemcpyAsync(rank_out, Xf, sizeof(double) * n, hipMemcpyDeviceToHost, g->stream));
+    RWR_HIP(hipStreamSynchronize(g->stream));
+    RWR_HIP(hipStreamSynchronize(g->stream2));
+    if (g->opts.profile) {
+        RWR_TRY(drain_events(a, &g->stats.spmm_ms));
+        RWR_TRY(drain_events(b, &g->stats.chain_ms));
+    }
+    return RWR_OK;
+}
+
+}  // namespace rwr

@@ -1,0 +1,267 @@
+"""Host-side mirror of the reference's public surface ``namespace Recommenders.RWRBased``
+(Recommenders/RWRBased/{Graph,Model,Recommender}.cs) over the librwr C-ABI.
+
+Same names, argument meaning and error behaviour as the C# types, so the parity tests read
+like the reference's caller (TweetRecommender/Experiment.cs:104-109).  The reference is
+C#, which cannot be built in this image; the C# shim that a .NET host would use is under
+csharp/ and P/Invokes exactly the functions used here.
+
+All arithmetic happens in hand-written HIP kernels on the GPU; this module only flattens the
+reference's containers into the SoA layout of include/rwr.h and wraps results.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+class NodeType(enum.IntEnum):
+    """Recommender.cs:4."""
+    UNDEFINED = 0
+    USER = 1
+    ITEM = 2
+    ETC = 3
+
+
+class EdgeType(enum.IntEnum):
+    """Recommender.cs:5."""
+    UNDEFINED = 0
+    LIKE = 1
+    FRIENDSHIP = 2
+    FOLLOW = 3
+    MENTION = 4
+    AUTHORSHIP = 5
+    PURCHASE = 6
+    ETC = 7
+
+
+class Node:
+    """struct Node (Graph.cs:4-17)."""
+    __slots__ = ("id", "type")
+
+    def __init__(self, id: int, type: NodeType = NodeType.UNDEFINED):
+        self.id = int(id)
+        self.type = NodeType(type)
+
+
+class ForwardLink:
+    """struct ForwardLink (Graph.cs:19-35); fields are public and mutable, as the harness
+    relies on (DataLoader.cs:66,424; Experiment.cs:90-97)."""
+    __slots__ = ("targetNode", "type", "weight")
+
+    def __init__(self, targetNode: int, type=EdgeType.UNDEFINED, weight: Optional[float] = None):
+        # ForwardLink(int, double) and ForwardLink(int, EdgeType, double)
+        if weight is None:
+            type, weight = EdgeType.UNDEFINED, type
+        self.targetNode = int(targetNode)
+        self.type = EdgeType(type)
+        self.weight = float(weight)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Graph:
+    """class Graph (Graph.cs:37-94).  ``nodes``/``edges`` are the caller's dictionaries
+    (kept by reference, Graph.cs:46-47); ``buildGraph()`` hands the RAW links to
+    rwr_graph_create, which filters/normalises/transposes on the device."""
+
+    def __init__(self, nodes: Dict[int, Node], edges: Dict[int, List[ForwardLink]], *, mode: Optional[str] = None,
+                 device: int = -1, tile_seeds: int = 0, tile_group: int = 0, profile: bool = False,
+                 workspace_bytes: int = 0):
+        self.nodes = nodes
+        self.edges = edges
+        self._graph_cache = None
+        self._h = C.c_void_p()
+        self._opts = _lib.rwr_opts(C.sizeof(_lib.rwr_opts), device,
+                                   {None: -1, "exact": _lib.RWR_MODE_EXACT, "fast": _lib.RWR_MODE_FAST}[mode],
+                                   tile_seeds, tile_group, 1 if profile else 0, workspace_bytes)
+        self._flat = None
+
+    # -- flat constructors (the layout of include/rwr.h), used by the bench for big graphs
+    @classmethod
+    def from_flat(cls, node_id, node_type, rowptr, dst, etype, w, **opts) -> "Graph":
+        g = cls(None, None, **opts)
+        g._flat = (np.ascontiguousarray(node_id, dtype=np.int64), np.ascontiguousarray(node_type, dtype=np.uint8),
+                   np.ascontiguousarray(rowptr, dtype=np.int64), np.ascontiguousarray(dst, dtype=np.int32),
+                   np.ascontiguousarray(etype, dtype=np.uint8), np.ascontiguousarray(w, dtype=np.float64))
+        return g
+
+    def _flatten(self):
+        n = len(self.nodes)
+        node_id = np.empty(n, dtype=np.int64)
+        node_type = np.empty(n, dtype=np.uint8)
+        for i in range(n):
+            nd = self.nodes[i]                 # keys must be 0..n-1 (Graph.cs:52,55)
+            node_id[i] = nd.id
+            node_type[i] = int(nd.type)
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        for i in range(n):
+            rowptr[i + 1] = rowptr[i] + (len(self.edges[i]) if i in self.edges else 0)
+        m = int(rowptr[n])
+        dst = np.empty(m, dtype=np.int32)
+        etype = np.empty(m, dtype=np.uint8)
+        w = np.empty(m, dtype=np.float64)
+        e = 0
+        for i in range(n):
+            if i in self.edges:
+                for l in self.edges[i]:
+                    dst[e] = l.targetNode
+                    etype[e] = int(l.type)
+                    w[e] = l.weight
+                    e += 1
+        return node_id, node_type, rowptr, dst, etype, w
+
+    def buildGraph(self) -> None:
+        """Graph.buildGraph (Graph.cs:51-88) -> rwr_graph_create."""
+        lib = _lib.load()
+        if self._h:
+            lib.rwr_graph_destroy(self._h)
+            self._h = C.c_void_p()
+        flat = self._flat if self._flat is not None else self._flatten()
+        node_id, node_type, rowptr, dst, etype, w = flat
+        self._n = int(node_id.shape[0])
+        self._rowptr = rowptr
+        _lib.check(lib.rwr_graph_create(self._n, _p(node_id, C.c_int64), _p(node_type, C.c_uint8),
+                                        _p(rowptr, C.c_int64), _p(dst, C.c_int32), _p(etype, C.c_uint8),
+                                        _p(w, C.c_double), C.byref(self._opts), C.byref(self._h)))
+        self._graph_cache = None
+
+    def size(self) -> int:
+        """Graph.size() (Graph.cs:91-93)."""
+        return len(self.nodes) if self.nodes is not None else int(self._flat[0].shape[0])
+
+    def _handle(self):
+        if not self._h:
+            raise RuntimeError("Graph.buildGraph() has not been called")
+        return self._h
+
+    def normalized(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(w_norm per raw link, dangling per node) -- rwr_graph_get_normalized."""
+        lib = _lib.load()
+        m = int(self._rowptr[-1])
+        wn = np.zeros(max(m, 1), dtype=np.float64)
+        dg = np.zeros(self._n, dtype=np.uint8)
+        _lib.check(lib.rwr_graph_get_normalized(self._handle(), _p(wn, C.c_double), _p(dg, C.c_uint8)))
+        return wn[:m], dg
+
+    @property
+    def graph(self) -> Dict[int, Optional[List[ForwardLink]]]:
+        """The public field Graph.graph (Graph.cs:43): normalised explicit links per node,
+        None for dangling nodes; materialised lazily from the device."""
+        if self._graph_cache is None:
+            wn, dg = self.normalized()
+            out = {}
+            flat = self._flat if self._flat is not None else self._flatten()
+            _, _, rowptr, dst, etype, _ = flat
+            for i in range(self._n):
+                if dg[i]:
+                    out[i] = None
+                else:
+                    out[i] = [ForwardLink(int(dst[e]), EdgeType(int(etype[e])), float(wn[e]))
+                              for e in range(int(rowptr[i]), int(rowptr[i + 1])) if etype[e] != 0]
+            self._graph_cache = out
+        return self._graph_cache
+
+    def stats(self) -> dict:
+        st = _lib.rwr_stats()
+        st.struct_size = C.sizeof(_lib.rwr_stats)
+        _lib.check(_lib.load().rwr_get_stats(self._handle(), C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def reset_stats(self) -> None:
+        _lib.check(_lib.load().rwr_reset_stats(self._handle()))
+
+    def close(self) -> None:
+        if self._h:
+            _lib.load().rwr_graph_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):   # the reference types have no Dispose: release on finalisation
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Model:
+    """class Model (Model.cs:5-116) backed by rwr_model_run."""
+
+    def __init__(self, graph: Graph, dampingFactor: float, targetNode: Optional[int] = None):
+        self.graph = graph
+        self.nNodes = graph.size()
+        self.dampingFactor = float(dampingFactor)
+        self._seed = -1 if targetNode is None else int(targetNode)
+        n = self.nNodes
+        if targetNode is None:                                  # Model.cs:14-31
+            self.rank = np.ones(n)
+            self.restart = np.full(n, 1.0 / n)
+        else:                                                   # Model.cs:33-50
+            self.rank = np.zeros(n)
+            self.restart = np.zeros(n)
+            if 0 <= targetNode < n:
+                self.rank[targetNode] = float(n)
+                self.restart[targetNode] = 1.0
+        self.nextRank = np.zeros(n)
+        self.iterations = 0
+
+    def run(self, arg=None) -> None:
+        """run(int) / run(double) / run()  (Model.cs:68-73, 57-66, 52-55)."""
+        lib = _lib.load()
+        if isinstance(arg, (int, np.integer)) and not isinstance(arg, bool):
+            mode, value = _lib.RWR_RUN_ITERATIONS, float(arg)
+        elif arg is None:
+            mode, value = _lib.RWR_RUN_DEFAULT_THRESHOLD, 0.0
+        else:
+            mode, value = _lib.RWR_RUN_THRESHOLD, float(arg)
+        out = np.zeros(self.nNodes, dtype=np.float64)
+        it = C.c_int64(0)
+        _lib.check(lib.rwr_model_run(self.graph._handle(), self._seed, self.dampingFactor, mode, value,
+                                     _p(out, C.c_double), C.byref(it)))
+        self.rank = out
+        self.nextRank = np.zeros(self.nNodes)
+        self.iterations = int(it.value)
+
+
+class Recommender:
+    """class Recommender (Recommender.cs:7-52)."""
+
+    def __init__(self, graph: Graph):
+        self.graph = graph
+
+    def Recommendation(self, idxTargetUser: int, dampingFactor: float, nIteration: int,
+                       topN: Optional[int] = None) -> List[Tuple[int, float]]:
+        """Recommendation(int, float, int[, int topN]) -> list of (item id, score), i.e. the
+        reference's List<KeyValuePair<long,double>> (Recommender.cs:14-40, 42-51)."""
+        g = self.graph
+        if g.edges is not None and idxTargetUser not in g.edges:
+            raise KeyError(idxTargetUser)        # graph.edges[idxTargetUser], Recommender.cs:21
+        lib = _lib.load()
+        cap = g.size()
+        ids = np.zeros(max(cap, 1), dtype=np.int64)
+        sc = np.zeros(max(cap, 1), dtype=np.float64)
+        cnt = C.c_int64(cap)
+        _lib.check(lib.rwr_recommend(g._handle(), int(idxTargetUser), C.c_float(dampingFactor), int(nIteration),
+                                     0 if topN is None else int(topN), _p(ids, C.c_int64), _p(sc, C.c_double),
+                                     C.byref(cnt)))
+        c = int(cnt.value)
+        return list(zip(ids[:c].tolist(), sc[:c].tolist()))
+
+    def RecommendationBatch(self, seeds, dampingFactor: float, nIteration: int, topN: int):
+        """Batch entry (an addition, see include/rwr.h): (ids[K,topN], scores[K,topN], counts[K])."""
+        lib = _lib.load()
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        K = int(seeds.shape[0])
+        ids = np.zeros((K, topN), dtype=np.int64)
+        sc = np.zeros((K, topN), dtype=np.float64)
+        counts = np.zeros(K, dtype=np.int32)
+        _lib.check(lib.rwr_recommend_batch(self.graph._handle(), _p(seeds, C.c_int32), K, C.c_float(dampingFactor),
+                                           int(nIteration), int(topN), _p(ids, C.c_int64), _p(sc, C.c_double),
+                                           _p(counts, C.c_int32)))
+        return ids, sc, counts

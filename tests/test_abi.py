@@ -1,0 +1,65 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol
+include/rwr.h declares; argument validation that needs no GPU; no compute is called."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    import __graft_entry__ as ge
+    from recommendersystems_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        ge.build()
+    return _lib
+
+
+def test_header_symbols_exported():
+    L = _lib()
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "rwr.h")).read()
+    declared = set(re.findall(r"\b(rwr_[a-z_]+)\s*\(", hdr))
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert b"gfx950" in lib.rwr_version()
+
+
+def test_struct_layouts_match_header():
+    L = _lib()
+    assert C.sizeof(L.rwr_opts) == 32
+    assert L.rwr_stats.nnz_raw.offset == 8 and L.rwr_stats.build_ms.offset == 40
+
+
+def test_argument_validation_without_gpu():
+    L = _lib()
+    lib = L.load()
+    out = C.c_void_p()
+    assert lib.rwr_graph_create(0, None, None, None, None, None, None, None, C.byref(out)) == L.RWR_E_INVALID
+    assert b"n must be > 0" in lib.rwr_last_error()
+    node_id = np.array([1, 2], dtype=np.int64)
+    node_type = np.array([1, 2], dtype=np.uint8)
+    rowptr = np.array([0, 2, 1], dtype=np.int64)     # decreasing
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    st = lib.rwr_graph_create(2, p(node_id, C.c_int64), p(node_type, C.c_uint8), p(rowptr, C.c_int64),
+                              None, None, None, None, C.byref(out))
+    assert st == L.RWR_E_INVALID
+    if lib.rwr_device_count() == 0:
+        rowptr = np.array([0, 0, 0], dtype=np.int64)
+        st = lib.rwr_graph_create(2, p(node_id, C.c_int64), p(node_type, C.c_uint8), p(rowptr, C.c_int64),
+                                  None, None, None, None, C.byref(out))
+        assert st == L.RWR_E_NO_DEVICE            # fails loudly: there is no CPU fallback
+        assert not out.value
+    assert lib.rwr_graph_destroy(None) == L.RWR_OK
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "recommendersystems_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
+                src = open(os.path.join(dp, f), errors="replace").read()
+                assert "rwr_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f

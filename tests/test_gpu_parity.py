@@ -1,0 +1,167 @@
+"""Parity tests proper: the HIP path, called through the C-ABI (ctypes), against the oracle
+on the same seeded inputs.  EXACT mode must be bitwise; FAST mode within 1e-6 with identical
+top-k lists."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import rwr_oracle as po
+from oracle.c_oracle import FlatGraph
+from tests import graphgen as gg
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import recommendersystems_amd as amd
+    from recommendersystems_amd import _lib
+    assert _lib.load().rwr_device_count() >= 1, "no gfx950 device: the HIP path cannot run"
+    return amd
+
+
+def dev_graph(amd, g, **opts):
+    G = amd.Graph.from_flat(**g, **opts)
+    G.buildGraph()
+    return G
+
+
+SMALL = [
+    dict(seed=1, n_users=12, n_items=30, n_likes=80, n_etc=3, n_friend=10, n_mention=12, n_author=8),
+    dict(seed=2, n_users=40, n_items=25, n_likes=300, n_etc=0, n_friend=30, n_mention=20, n_author=10),
+    dict(seed=3, n_users=5, n_items=60, n_likes=40, n_etc=2, p_undefined=0.3, n_mention=6),
+    dict(seed=4, n_users=30, n_items=90, n_likes=400, uniform=True),
+]
+MEDIUM = [
+    dict(seed=11, n_users=700, n_items=2500, n_likes=20000, n_etc=20, n_friend=800, n_mention=500, n_author=300),
+    dict(seed=12, n_users=3000, n_items=1000, n_likes=60000, uniform=True),
+]
+
+
+def test_kats_via_mirror_classes(amd):
+    """SURVEY.md section 8c KATs through the reference-shaped classes (dict containers)."""
+    for kat, seed_rank, rec_expect in ((gg.kat1(), [2.25, 1.375, 0.25, 0.125], [(13, 0.125)]),
+                                       (gg.kat2(), [1.25, 0.75], [])):
+        nodes = {i: amd.Node(int(kat["node_id"][i]), amd.NodeType(int(kat["node_type"][i])))
+                 for i in range(len(kat["node_id"]))}
+        edges = {i: [amd.ForwardLink(int(kat["dst"][e]), amd.EdgeType.LIKE, 1.0)
+                     for e in range(kat["rowptr"][i], kat["rowptr"][i + 1])] for i in range(len(nodes))}
+        graph = amd.Graph(nodes, edges)
+        graph.buildGraph()
+        model = amd.Model(graph, 0.5, 0)
+        model.run(3)
+        assert model.rank.tolist() == seed_rank
+        assert amd.Recommender(graph).Recommendation(0, 0.5, 3) == rec_expect
+
+
+@pytest.mark.parametrize("case", SMALL + MEDIUM, ids=lambda c: f"g{c['seed']}")
+def test_build_graph_bitwise(amd, case):
+    g = gg.random_graph(**case)
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g)
+    wn, dg = G.normalized()
+    assert (bits(wn) == bits(F.w_norm)).all()
+    assert (dg == F.dangling).all()
+    st = G.stats()
+    assert st["nnz"] == int((g["etype"] != 0).sum())
+    assert st["uniform"] == (1 if case.get("uniform") else 0) or not case.get("uniform")
+
+
+@pytest.mark.parametrize("case", SMALL, ids=lambda c: f"g{c['seed']}")
+@pytest.mark.parametrize("tile_seeds", [0, 1, 4, 16, 64])
+def test_small_exact_bitwise_vs_literal_python(amd, case, tile_seeds):
+    g = gg.random_graph(**case)
+    nodes, edges = po.from_flat(g["node_id"], g["node_type"], g["rowptr"], g["dst"], g["etype"], g["w"])
+    PG = po.Graph(nodes, edges)
+    PG.buildGraph()
+    G = dev_graph(amd, g, tile_seeds=tile_seeds)
+    rec = amd.Recommender(G)
+    n = len(nodes)
+    for seed in (0, n // 3, case["n_users"] - 1):
+        for T in (0, 1, 2, 5, 10):
+            m = po.Model(PG, po.widen_float(0.15), seed, dense_restart=True)
+            m.run(T)
+            dm = amd.Model(G, po.widen_float(0.15), seed)
+            dm.run(T)
+            assert (bits(dm.rank) == bits(m.rank)).all(), (seed, T)
+        ref = po.Recommender(PG).Recommendation(seed, 0.15, 10)
+        got = rec.Recommendation(seed, 0.15, 10)
+        assert [r[0] for r in got] == [r[0] for r in ref]
+        assert (bits([r[1] for r in got]) == bits([r[1] for r in ref])).all()
+        assert rec.Recommendation(seed, 0.15, 10, 7) == got[:7]
+        assert rec.Recommendation(seed, 0.15, 10, 0) == got          # topN <= 0 -> whole list
+        assert rec.Recommendation(seed, 0.15, 10, 10 ** 6) == got
+
+
+@pytest.mark.parametrize("case", MEDIUM, ids=lambda c: f"g{c['seed']}")
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_medium_batch_vs_c_oracle(amd, case, mode):
+    g = gg.random_graph(**case)
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g, mode=mode)
+    rec = amd.Recommender(G)
+    K = 70
+    seeds = np.linspace(0, case["n_users"] - 1, K).astype(np.int32)
+    ids, sc, cnt = rec.RecommendationBatch(seeds, 0.15, 10, 25)
+    oi, os_, oc = F.recommend_batch(seeds, 0.15, 10, 25)
+    assert (cnt == oc).all()
+    assert (ids == oi).all()                       # top-k id lists identical in both modes
+    if mode == "exact":
+        assert (bits(sc) == bits(os_)).all()
+    else:
+        assert np.abs(sc - os_).max() <= 1e-6      # north_star: rank scores within 1e-6
+    # single-seed full list == batch prefix
+    full = rec.Recommendation(int(seeds[5]), 0.15, 10)
+    assert [r[0] for r in full[:cnt[5]]] == ids[5, :cnt[5]].tolist()
+    fi, fs = F.recommend(int(seeds[5]), 0.15, 10)
+    assert [r[0] for r in full] == fi.tolist()
+    if mode == "exact":
+        assert (bits([r[1] for r in full]) == bits(fs)).all()
+
+
+def test_properties_exact(amd):
+    g = gg.random_graph(21, n_users=400, n_items=1500, n_likes=9000, n_friend=300, n_mention=200)
+    G = dev_graph(amd, g)
+    n = len(g["node_id"])
+    m = amd.Model(G, po.widen_float(0.15), 5)
+    m.run(10)
+    assert abs(m.rank.sum() - n) < 1e-9 * n                      # mass n conserved
+    rec = amd.Recommender(G).Recommendation(5, 0.15, 10)
+    liked = {int(g["dst"][e]) for e in range(g["rowptr"][5], g["rowptr"][6]) if g["etype"][e] == gg.EDGE_LIKE}
+    liked_ids = {int(g["node_id"][j]) for j in liked}
+    assert not (liked_ids & {r[0] for r in rec})                 # exclusion list never appears
+    keys = [(-r[1], -r[0]) for r in rec]
+    assert keys == sorted(keys)                                  # (score desc, id desc)
+    n_items = int((g["node_type"] == gg.NODE_ITEM).sum())
+    assert len(rec) == n_items - len({j for j in liked if g["node_type"][j] == gg.NODE_ITEM})
+
+
+def test_error_behaviour(amd):
+    from recommendersystems_amd import _lib
+    g = gg.kat1()
+    G = dev_graph(amd, g)
+    with pytest.raises(amd.RwrError) as ei:
+        amd.Recommender(G).Recommendation(99, 0.5, 3)
+    assert ei.value.status == _lib.RWR_E_RANGE
+    bad = dict(g)
+    bad["dst"] = g["dst"].copy()
+    bad["dst"][0] = 77
+    with pytest.raises(amd.RwrError) as ei:
+        dev_graph(amd, bad)
+    assert ei.value.status == _lib.RWR_E_RANGE
+    # KeyNotFoundException analogue on the dictionary form (Recommender.cs:21)
+    nodes = {0: amd.Node(1, amd.NodeType.USER), 1: amd.Node(2, amd.NodeType.ITEM)}
+    graph = amd.Graph(nodes, {1: []})
+    graph.buildGraph()
+    with pytest.raises(KeyError):
+        amd.Recommender(graph).Recommendation(0, 0.5, 1)
+    # capacity error reports the needed size
+    lib = _lib.load()
+    cnt = C.c_int64(0)
+    st = lib.rwr_recommend(G._handle(), 0, C.c_float(0.5), 3, 0, None, None, C.byref(cnt))
+    assert st == _lib.RWR_E_CAPACITY and cnt.value == 1
