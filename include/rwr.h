@@ -97,7 +97,8 @@ typedef struct rwr_stats {
     double  chain_ms;        /* exact-mode seed-row kernel / fast-mode restart reduction        */
     int64_t chain_launches;
     double  rank_ms;         /* exclusion mask + top-k / sort + gather                          */
-    double  iterate_wall_ms; /* host wall time of the iterate phase (stream-synchronised)       */
+    double  iterate_wall_ms; /* device time from the first to the last event of the iterate
+                                phase (SpMM and seed-row kernels overlapped)                    */
     double  total_wall_ms;   /* host wall time inside rwr_recommend* calls                      */
     int64_t seeds_done;
 } rwr_stats;

@@ -392,17 +392,16 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
     RWR_HIP(hipMemsetAsync(g->d_counts.p, 0, (size_t)ntiles * G * sizeof(int32_t), s));
 
     EvPool pool;
-    std::vector<hipEvent_t> spmm_ev, chain_ev, rank_ev;
+    std::vector<hipEvent_t> spmm_ev, chain_ev, rank_ev, iter_ev;
     const bool prof = g->opts.profile != 0;
-    double iter_wall = 0.0;
     for (int t0 = 0; t0 < ntiles; t0 += TG) {
         const int tg = (ntiles - t0 < TG) ? (ntiles - t0) : TG;
         const int32_t *dseeds = g->d_seeds.p + (size_t)t0 * G;
         double *Xf = nullptr;
-        double w0 = 0;
-        if (prof) { RWR_HIP(hipStreamSynchronize(s)); w0 = now_ms(); }
+        hipEvent_t i0 = nullptr, i1 = nullptr;
+        if (prof) { i0 = pool.get(); i1 = pool.get(); RWR_HIP(hipEventRecord(i0, s)); }
         RWR_TRY(iterate_group(g, G, tg, dseeds, d, n_iter, &Xf, pool, spmm_ev, chain_ev));
-        if (prof) { RWR_HIP(hipStreamSynchronize(s)); iter_wall += now_ms() - w0; }
+        if (prof) { RWR_HIP(hipEventRecord(i1, s)); iter_ev.push_back(i0); iter_ev.push_back(i1); }
         int32_t real = K - t0 * G;
         if (real > tg * G) real = tg * G;
         g->stats.spmm_seed_steps += (int64_t)real * n_iter;
@@ -434,7 +433,7 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
         RWR_TRY(drain_events(spmm_ev, &g->stats.spmm_ms));
         RWR_TRY(drain_events(chain_ev, &g->stats.chain_ms));
         RWR_TRY(drain_events(rank_ev, &g->stats.rank_ms));
-        g->stats.iterate_wall_ms += iter_wall;
+        RWR_TRY(drain_events(iter_ev, &g->stats.iterate_wall_ms));
     }
     g->stats.tile_seeds = G;
     g->stats.tile_group = TG;
