@@ -10,6 +10,8 @@
 // the order in which Model.deliverRanks adds into nextRank[target] (Model.cs:78,85-88).
 #include "engine.h"
 
+#include <cstdlib>
+
 namespace rwr {
 
 // one thread per source row; sequential within the row (the sum order is part of the contract)
@@ -80,12 +82,14 @@ __global__ __launch_bounds__(256) void k_order_keys(int32_t n, const int64_t *__
                                                     const int64_t *__restrict__ node_id,
                                                     uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval,
                                                     uint64_t *__restrict__ ikey, uint32_t *__restrict__ ival,
-                                                    int *__restrict__ maxdeg)
+                                                    int *__restrict__ maxdeg, int order_mode)
 {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t deg = (uint32_t)(in_ptr[i + 1] - in_ptr[i]);
-    dkey[i] = ~deg;            // ascending sort of ~deg == in-degree descending
+    // ascending sort of ~deg == in-degree descending; mode 2: by power-of-two degree class only
+    // (stable, so rows keep their natural order inside a class); mode 1: natural order
+    dkey[i] = (order_mode == 1) ? 0u : (order_mode == 2) ? ~(uint32_t)(32 - __clz((int)deg)) : ~deg;
     dval[i] = (uint32_t)i;
     // items by id descending: ascending sort of ~orderable(id); non-items last
     ikey[i] = (node_type[i] == RWR_NODE_ITEM) ? ~i64_orderable(node_id[i]) : ~0ull;
@@ -194,6 +198,8 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     }
 
     // destination-row processing order (in-degree descending) and ITEM rows by id descending
+    const char *om = getenv("RWR_ROW_ORDER");
+    const int order_mode = om ? atoi(om) : 0;
     DevBuf<uint64_t> ikey, ikey2;
     DevBuf<uint32_t> ival, ival2;
     RWR_TRY(ikey.alloc(n));
@@ -201,7 +207,7 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     RWR_TRY(ival.alloc(n));
     RWR_TRY(ival2.alloc(n));
     hipLaunchKernelGGL(k_order_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->in_ptr.p, g->node_type.p,
-                       g->node_id.p, skey.p, sval.p, ikey.p, ival.p, flags.p + 2);
+                       g->node_id.p, skey.p, sval.p, ikey.p, ival.p, flags.p + 2, order_mode);
     RWR_HIP(hipGetLastError());
     RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, 32, temp.p, s, &alt));
     hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p, g->row_order.p,

@@ -24,6 +24,7 @@
 
 #include <chrono>
 #include <climits>
+#include <cstdlib>
 
 namespace rwr {
 
@@ -74,6 +75,75 @@ __global__ __launch_bounds__(256) void k_spmm(int32_t n, const int64_t *__restri
         for (; p < e; ++p) {
             double rw = c1 * X[(size_t)in_src[p] * G + k];
             acc += rw * in_w[p];
+        }
+        if (j >= 0 && j != my_seed) Y[(size_t)j * G + k] = acc;
+    }
+}
+
+// Chunked variant for G >= 8: a lane group fetches G consecutive in-neighbour indices (and
+// weights) of its row with ONE coalesced load -- lane k takes entry p+k -- and hands entry t
+// to the whole group through the LDS crossbar (ds_bpermute), instead of G lanes loading the
+// same address per edge.  All G row gathers of a chunk are issued before the first add, so
+// each lane keeps up to G 8-byte gathers in flight; the adds then run in list order.
+template <int G, int CH>
+__global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *__restrict__ in_ptr,
+                                                      const int32_t *__restrict__ in_src,
+                                                      const double *__restrict__ in_w,
+                                                      const int32_t *__restrict__ row_order,
+                                                      const double *__restrict__ X, double *__restrict__ Y,
+                                                      const int32_t *__restrict__ seeds, double c1,
+                                                      int skip_seed_row)
+{
+    static_assert(G >= 8 && G <= 64, "chunked SpMM needs 8 <= G <= 64");
+    constexpr int RPW = WAVE / G;
+    const int tile = blockIdx.y;
+    const size_t toff = (size_t)tile * (size_t)n * G;
+    X += toff;
+    Y += toff;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int sub = lane / G, k = lane % G;
+    const int gbase = (lane - k) << 2;      // byte address of the group's lane 0 for ds_bpermute
+    const int32_t my_seed = skip_seed_row ? seeds[tile * G + k] : -1;
+    const int wpb = blockDim.x / WAVE;
+    const int64_t nwaves = (int64_t)gridDim.x * wpb;
+    for (int64_t rb = ((int64_t)blockIdx.x * wpb + threadIdx.x / WAVE) * RPW; rb < n; rb += nwaves * RPW) {
+        const int64_t r = rb + sub;
+        int32_t j = -1;
+        int64_t p = 0, e = 0;
+        if (r < n) {
+            j = row_order[r];
+            p = in_ptr[j];
+            e = in_ptr[j + 1];
+        }
+        double acc = 0.0;
+        // the wave iterates while ANY group still has entries; finished groups idle (cnt = 0)
+        while (__any(p < e)) {
+            const int64_t left = e - p;
+            const int cnt = left > CH ? CH : (left > 0 ? (int)left : 0);
+            int32_t my_idx = 0;
+            double my_w = 0.0;
+            if (k < cnt) {
+                my_idx = in_src[p + k];
+                my_w = in_w[p + k];
+            }
+            const int wlo = __double2loint(my_w), whi = __double2hiint(my_w);
+            double xv[CH], wv[CH];
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int idx = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), my_idx);
+                const int lo = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), wlo);
+                const int hi = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), whi);
+                wv[t] = __hiloint2double(hi, lo);
+                xv[t] = (t < cnt) ? X[(size_t)idx * G + k] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                if (t < cnt) {
+                    double rw = c1 * xv[t];      // Model.cs:84
+                    acc += rw * wv[t];           // Model.cs:87
+                }
+            }
+            p += cnt;
         }
         if (j >= 0 && j != my_seed) Y[(size_t)j * G + k] = acc;
     }
@@ -131,6 +201,114 @@ __global__ __launch_bounds__(64) void k_seed_chain(int32_t n, int ntiles, const 
         acc += dangling[i] ? xi : (xi - rw);
     }
     Y[(size_t)tile * (size_t)n * G + (size_t)s * G + k] = acc;
+}
+
+// EXACT mode, pipelined form of k_seed_chain: one 256-thread workgroup per tile.
+// All four waves stream the tile's rank matrix in 64 KiB chunks (coalesced, 32 loads in
+// flight per lane), turn each value into its restart addend
+//     rr_i = dangling_i ? x_i : x_i - (1-d)*x_i          (Model.cs:91,97)
+// and stage it in LDS (double-buffered); wave 0 then folds the staged addends into the
+// per-seed accumulators strictly in node order -- the n-term fp64 chain itself is
+// inherently sequential, so it runs at the dependent-add rate while the other waves hide
+// the memory latency.  Chunks that contain a source linking INTO a seed take the careful
+// path, which interleaves that link's addend before the node's restart addend exactly
+// as Model.cs:85-93 does.
+constexpr int CHAIN_CE = 8192;                 // doubles per chunk (64 KiB)
+constexpr int CHAIN_LPT = CHAIN_CE / 256;      // loads per thread per chunk
+template <int G>
+__global__ __launch_bounds__(256) void k_seed_chain_lds(int32_t n, const int64_t *__restrict__ in_ptr,
+                                                        const int32_t *__restrict__ in_src,
+                                                        const double *__restrict__ in_w,
+                                                        const uint8_t *__restrict__ dangling,
+                                                        const double *__restrict__ X, double *__restrict__ Y,
+                                                        const int32_t *__restrict__ seeds, double c1)
+{
+    constexpr int CR = CHAIN_CE / G;           // rows per chunk
+    extern __shared__ double chain_buf[];      // [2][CHAIN_CE]
+    const int tile = blockIdx.x;
+    const double *x = X + (size_t)tile * (size_t)n * G;
+    const int tid = threadIdx.x;
+    const int64_t total = (int64_t)n * G;      // doubles in the tile
+    const int nchunks = (int)((total + CHAIN_CE - 1) / CHAIN_CE);
+
+    // consumer state (meaningful in wave 0, lanes < G)
+    const bool consumer = tid < G;
+    const int k = tid % G;
+    int32_t s = -1;
+    int64_t p = 0, e = 0;
+    int32_t nxt = INT_MAX;
+    if (consumer) {
+        s = seeds[tile * G + k];
+        if (s >= 0) {
+            p = in_ptr[s];
+            e = in_ptr[s + 1];
+            nxt = (p < e) ? in_src[p] : INT_MAX;
+        }
+    }
+    double acc = 0.0;
+
+    // branch-free, clamped loads so that all 2*CHAIN_LPT loads of a chunk are in flight together
+    double reg[CHAIN_LPT];
+    uint8_t dreg[CHAIN_LPT];
+    auto load_chunk = [&](int c) {
+        const int64_t base = (int64_t)c * CHAIN_CE;
+#pragma unroll
+        for (int q = 0; q < CHAIN_LPT; ++q) {
+            int64_t el = base + (int64_t)q * 256 + tid;
+            el = el < total ? el : total - 1;
+            reg[q] = x[el];
+            dreg[q] = dangling[el / G];
+        }
+    };
+    auto stage_chunk = [&](int c) {
+        const int64_t base = (int64_t)c * CHAIN_CE;
+        double *buf = chain_buf + (size_t)(c & 1) * CHAIN_CE;
+#pragma unroll
+        for (int q = 0; q < CHAIN_LPT; ++q) {
+            const int off = q * 256 + tid;
+            const double xv = (base + off < total) ? reg[q] : 0.0;   // past the end: +0.0, changes nothing
+            const double rw = c1 * xv;
+            buf[off] = dreg[q] ? xv : (xv - rw);
+        }
+    };
+
+    load_chunk(0);
+    for (int c = 0; c < nchunks; ++c) {
+        stage_chunk(c);
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        __syncthreads();
+        if (tid < WAVE) {   // wave 0 folds chunk c
+            const double *buf = chain_buf + (size_t)(c & 1) * CHAIN_CE;
+            const int64_t row0 = (int64_t)c * CR;
+            // 16-row sub-blocks: the common one has no link into any seed of the tile and is a pure
+            // add chain; the rare one checks every row (per-lane) for pending in-links
+            for (int r0 = 0; r0 < CR; r0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = buf[(r0 + u) * G + k];
+                const bool evt = __any(consumer && nxt < row0 + r0 + 16);
+                if (!evt) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc += v[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int64_t i = row0 + r0 + u;
+                        while (consumer && nxt == i) {           // links i -> seed come first (Model.cs:85-88)
+                            const double rw = c1 * x[(size_t)i * G + k];
+                            acc += rw * in_w[p];
+                            ++p;
+                            nxt = (p < e) ? in_src[p] : INT_MAX;
+                        }
+                        acc += v[u];                             // then the restart addend (Model.cs:91-93,96-97)
+                    }
+                }
+            }
+        }
+        // no second barrier: chunk c+2 is staged into this buffer only after every wave has passed
+        // the barrier of phase c+1, which wave 0 reaches after finishing this fold
+    }
+    if (consumer && s >= 0) Y[(size_t)tile * (size_t)n * G + (size_t)s * G + k] = acc;
 }
 
 // FAST mode: restart mass R_k = sum_i (dangling_i ? x_i : x_i - (1-d) x_i), deterministic tree.
@@ -210,6 +388,19 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
     constexpr int RPW = WAVE / G;
     unsigned want = cdiv((size_t)g->n, (size_t)RPW * 4);
     unsigned gx = want < 8192u ? want : 8192u;
+    static const int variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
+    if constexpr (G >= 8) {
+        if (variant == 1) {
+            hipLaunchKernelGGL((k_spmm_chunked<G, (G > 16 ? 16 : G)>), dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p,
+                               g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip);
+            return;
+        }
+        if (variant == 2) {
+            hipLaunchKernelGGL((k_spmm_chunked<G, 8>), dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p,
+                               g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip);
+            return;
+        }
+    }
     hipLaunchKernelGGL(k_spmm<G>, dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p, g->in_w.p,
                        g->row_order.p, X, Y, seeds, c1, skip);
 }
@@ -217,6 +408,17 @@ template <int G>
 static void launch_chain(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
                          hipStream_t s)
 {
+    static const int variant = [] { const char *e = getenv("RWR_CHAIN"); return e ? atoi(e) : 1; }();
+    if (variant == 1) {
+        static const bool attr_ok = [] {
+            return hipFuncSetAttribute((const void *)k_seed_chain_lds<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * CHAIN_CE * (int)sizeof(double)) == hipSuccess;
+        }();
+        (void)attr_ok;
+        hipLaunchKernelGGL(k_seed_chain_lds<G>, dim3(tg), dim3(256), 2 * CHAIN_CE * sizeof(double), s, g->n,
+                           g->in_ptr.p, g->in_src.p, g->in_w.p, g->dangling.p, X, Y, seeds, c1);
+        return;
+    }
     hipLaunchKernelGGL(k_seed_chain<G>, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, g->n, tg, g->in_ptr.p,
                        g->in_src.p, g->in_w.p, g->dangling.p, X, Y, seeds, c1);
 }
