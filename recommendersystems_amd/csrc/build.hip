@@ -97,6 +97,15 @@ __global__ __launch_bounds__(256) void k_order_keys(int32_t n, const int64_t *__
     atomicMax(maxdeg, (int)deg);
 }
 
+__global__ void k_item_flag_keys(int32_t n, const uint8_t *__restrict__ node_type, uint32_t *__restrict__ key,
+                                 uint32_t *__restrict__ val)
+{
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key[i] = (node_type[i] == RWR_NODE_ITEM) ? 0u : 1u;
+    val[i] = (uint32_t)i;
+}
+
 __global__ void k_u32_to_i32(const uint32_t *__restrict__ a, int32_t *__restrict__ b, int64_t m)
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,6 +145,7 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     RWR_TRY(g->in_ptr.alloc((size_t)n + 1));
     RWR_TRY(g->row_order.alloc(n));
     RWR_TRY(g->item_order.alloc(n_items));
+    RWR_TRY(g->item_rows.alloc(n_items));
 
     DevBuf<double> w_raw;
     DevBuf<int32_t> esrc;
@@ -212,6 +222,12 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, 32, temp.p, s, &alt));
     hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p, g->row_order.p,
                        (int64_t)n);
+    // ITEM rows in ascending row order: one stable pass on the flag (item ? 0 : 1)
+    hipLaunchKernelGGL(k_item_flag_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->node_type.p, skey.p, sval.p);
+    RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, 8, temp.p, s, &alt));
+    if (n_items > 0)
+        hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n_items, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p,
+                           g->item_rows.p, (int64_t)n_items);
     RWR_TRY(radix_sort_pairs<uint64_t>(ikey.p, ikey2.p, ival.p, ival2.p, (size_t)n, 1, 64, temp.p, s, &alt));
     if (n_items > 0)
         hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n_items, 256)), dim3(256), 0, s, alt ? ival2.p : ival.p,

@@ -31,6 +31,7 @@ struct rwr_graph {
     rwr::DevBuf<uint8_t> dangling;    // graph[i] == null (Graph.cs:53,86)
     rwr::DevBuf<int32_t> row_order;   // destination rows by in-degree descending (stable)
     rwr::DevBuf<int32_t> item_order;  // ITEM rows by id descending
+    rwr::DevBuf<int32_t> item_rows;   // ITEM rows by row index ascending
 
     // batch workspace (lazily sized)
     rwr::DevBuf<double> X, Y;         // rank matrices [tile][n][G]

@@ -466,6 +466,9 @@ struct EvPool {
 };
 
 // declared in rank.hip
+int32_t rank_group_select(rwr_graph *g, int G, int tg, int64_t first_seed_slot, int32_t n_real, int32_t top_n,
+                          const double *X, const int32_t *d_seeds, hipStream_t s);
+int rank_select_max_k();
 int32_t rank_tile(rwr_graph *g, int G, int tile_in_group, int64_t first_seed_slot, int32_t n_real, int32_t top_n,
                   const double *X, const int32_t *d_seeds_tile, hipStream_t s);
 
@@ -612,11 +615,16 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
         hipLaunchKernelGGL(k_exclude, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, g->rowptr.p,
                            g->dst.p, g->etype.p, Xf, dseeds);
         RWR_HIP(hipGetLastError());
-        for (int t = 0; t < tg; ++t) {
-            int32_t n_real = K - (t0 + t) * G;
-            if (n_real > G) n_real = G;
-            RWR_TRY(rank_tile(g, G, t, (int64_t)(t0 + t) * G, n_real, top_n, Xf + (size_t)t * (size_t)n * G,
-                              dseeds + (size_t)t * G, s));
+        static const int force_sort = [] { const char *e = getenv("RWR_RANK_SORT"); return e ? atoi(e) : 0; }();
+        if (top_n <= rank_select_max_k() && !force_sort) {
+            RWR_TRY(rank_group_select(g, G, tg, (int64_t)t0 * G, real, top_n, Xf, dseeds, s));
+        } else {
+            for (int t = 0; t < tg; ++t) {
+                int32_t n_real = K - (t0 + t) * G;
+                if (n_real > G) n_real = G;
+                RWR_TRY(rank_tile(g, G, t, (int64_t)(t0 + t) * G, n_real, top_n, Xf + (size_t)t * (size_t)n * G,
+                                  dseeds + (size_t)t * G, s));
+            }
         }
         if (prof) { RWR_HIP(hipEventRecord(b, s)); rank_ev.push_back(a); rank_ev.push_back(b); }
     }

@@ -63,6 +63,215 @@ __global__ __launch_bounds__(256) void k_rank_emit(int32_t n_items, int G, int32
     out_score[(size_t)k * top_n + q] = X[(size_t)row * G + k];
 }
 
+// ---------------------------------------------------------------------------------------
+// Batched top-k without sorting everything: MSD radix SELECT on the 128-bit key
+// (score, id) -- 8-bit digits from the top, one histogram pass per level over the tile's
+// candidates -- until the bin holding the k-th best entry has at most SEL_CAP members;
+// then every entry at or above that bin is collected (at most k-1+SEL_CAP) and only those
+// are sorted (bitonic, in LDS).  Integer counting only: the result is exactly the first
+// top_n entries of the full (score desc, id desc) order of Recommender.cs:35-38.
+// Typical depth is two levels (sign/exponent byte, then 4 exponent + 4 mantissa bits).
+// ---------------------------------------------------------------------------------------
+constexpr int SEL_MAX_K = 1024;
+constexpr int SEL_CAP = 3072;
+constexpr int SEL_SLOTS = 4096;      // >= SEL_MAX_K - 1 + SEL_CAP
+constexpr int SEL_LEVELS = 16;
+constexpr int SEL_ROWS_PER_BLOCK = 4096;
+
+struct SelState {
+    uint64_t ph, pl;     // prefix: nbits <= 64: ph holds the top nbits of the score key (right-aligned);
+                         // nbits > 64: ph = full score key, pl = top (nbits-64) bits of the id key
+    int32_t nbits;       // bits decided so far
+    int32_t k_rem;       // entries still to take from inside the prefix bin
+    int32_t total;       // candidates of the segment (set at level 0)
+    int32_t done;
+    int32_t cand_cnt;    // collect cursor
+    int32_t pad;
+};
+
+__device__ static inline int sel_cmp(uint64_t hi, uint64_t lo, const SelState &st)
+{
+    if (st.nbits == 0) return 0;
+    if (st.nbits <= 64) {
+        const uint64_t a = hi >> (64 - st.nbits);
+        return a > st.ph ? 1 : (a < st.ph ? -1 : 0);
+    }
+    if (hi != st.ph) return hi > st.ph ? 1 : -1;
+    const uint64_t b = lo >> (128 - st.nbits);
+    return b > st.pl ? 1 : (b < st.pl ? -1 : 0);
+}
+
+__global__ void k_sel_init(int nseg, int32_t top_n, const int32_t *__restrict__ seeds, SelState *__restrict__ st)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nseg) return;
+    SelState s{};
+    s.k_rem = top_n;
+    s.done = seeds[q] < 0 ? 1 : 0;
+    st[q] = s;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_sel_hist(int32_t n, int32_t n_items, const int32_t *__restrict__ item_rows,
+                                                  const int64_t *__restrict__ node_id,
+                                                  const double *__restrict__ X, const SelState *__restrict__ st,
+                                                  uint32_t *__restrict__ ghist, int level)
+{
+    constexpr int RL = 256 / G;
+    __shared__ uint32_t h[G][256];
+    __shared__ SelState sst[G];
+    __shared__ int any_active;
+    const int tile = blockIdx.y;
+    const int tid = threadIdx.x, k = tid % G, rl = tid / G;
+    if (tid == 0) any_active = 0;
+    __syncthreads();
+    if (tid < G) {
+        sst[tid] = st[tile * G + tid];
+        if (!sst[tid].done) any_active = 1;
+    }
+    __syncthreads();
+    if (!any_active) return;
+    for (int b = rl; b < 256; b += RL) h[k][b] = 0;
+    __syncthreads();
+    const double *x = X + (size_t)tile * (size_t)n * G;
+    const SelState my = sst[k];
+    const int32_t q0 = blockIdx.x * SEL_ROWS_PER_BLOCK;
+    const int32_t q1 = (q0 + SEL_ROWS_PER_BLOCK < n_items) ? q0 + SEL_ROWS_PER_BLOCK : n_items;
+    if (!my.done) {
+        for (int32_t q = q0 + rl; q < q1; q += RL) {
+            const int32_t row = item_rows[q];
+            const double s = x[(size_t)row * G + k];
+            if (!(s >= 0.0)) continue;                       // excluded (Recommender.cs:29)
+            const uint64_t hi = f64_orderable(s);
+            uint64_t lo = 0;
+            if (level >= 8) lo = i64_orderable(node_id[row]);
+            if (sel_cmp(hi, lo, my) != 0) continue;
+            const unsigned digit = (level < 8) ? (unsigned)(hi >> (56 - 8 * level)) & 255u
+                                               : (unsigned)(lo >> (56 - 8 * (level - 8))) & 255u;
+            atomicAdd(&h[k][digit], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = rl; b < 256; b += RL) {
+        const uint32_t c = h[k][b];
+        if (c) atomicAdd(&ghist[((size_t)tile * G + k) * 256 + b], c);
+    }
+}
+
+__global__ void k_sel_decide(int nseg, SelState *__restrict__ st, uint32_t *__restrict__ ghist, int level)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nseg) return;
+    SelState s = st[q];
+    uint32_t *h = ghist + (size_t)q * 256;
+    if (s.done) return;
+    if (level == 0) {
+        int64_t tot = 0;
+        for (int b = 0; b < 256; ++b) tot += h[b];
+        s.total = (int32_t)tot;
+        if (tot <= s.k_rem) {                  // fewer candidates than top_n: take them all
+            s.k_rem = (int32_t)tot;
+            s.done = 1;                        // nbits stays 0: every key matches the empty prefix
+            for (int b = 0; b < 256; ++b) h[b] = 0;
+            st[q] = s;
+            return;
+        }
+    }
+    int64_t cum = 0;
+    int sel = 0;
+    uint32_t bin = 0;
+    for (int b = 255; b >= 0; --b) {
+        const uint32_t c = h[b];
+        if (cum + c >= (int64_t)s.k_rem) { sel = b; bin = c; break; }
+        cum += c;
+    }
+    for (int b = 0; b < 256; ++b) h[b] = 0;
+    s.k_rem -= (int32_t)cum;                   // entries above the chosen bin are all taken
+    if (level < 8) s.ph = (s.ph << 8) | (uint64_t)sel;
+    else s.pl = (s.pl << 8) | (uint64_t)sel;
+    s.nbits += 8;
+    if (bin <= (uint32_t)SEL_CAP || level == SEL_LEVELS - 1) s.done = 1;
+    st[q] = s;
+}
+
+struct SelCand {
+    uint64_t hi, lo;
+};
+
+template <int G>
+__global__ __launch_bounds__(256) void k_sel_collect(int32_t n, int32_t n_items, const int32_t *__restrict__ item_rows,
+                                                     const int64_t *__restrict__ node_id,
+                                                     const double *__restrict__ X, SelState *__restrict__ st,
+                                                     const int32_t *__restrict__ seeds, SelCand *__restrict__ cand)
+{
+    constexpr int RL = 256 / G;
+    __shared__ SelState sst[G];
+    const int tile = blockIdx.y;
+    const int tid = threadIdx.x, k = tid % G, rl = tid / G;
+    if (tid < G) sst[tid] = st[tile * G + tid];
+    __syncthreads();
+    if (seeds[tile * G + k] < 0) return;
+    const SelState my = sst[k];
+    const double *x = X + (size_t)tile * (size_t)n * G;
+    const int32_t q0 = blockIdx.x * SEL_ROWS_PER_BLOCK;
+    const int32_t q1 = (q0 + SEL_ROWS_PER_BLOCK < n_items) ? q0 + SEL_ROWS_PER_BLOCK : n_items;
+    for (int32_t q = q0 + rl; q < q1; q += RL) {
+        const int32_t row = item_rows[q];
+        const double s = x[(size_t)row * G + k];
+        if (!(s >= 0.0)) continue;
+        const uint64_t hi = f64_orderable(s);
+        if (my.nbits > 0 && my.nbits <= 64 && (hi >> (64 - my.nbits)) < my.ph) continue;   // cheap reject
+        const uint64_t lo = i64_orderable(node_id[row]);
+        if (sel_cmp(hi, lo, my) < 0) continue;
+        const int slot = atomicAdd(&st[tile * G + k].cand_cnt, 1);
+        if (slot < SEL_SLOTS) cand[((size_t)tile * G + k) * SEL_SLOTS + slot] = SelCand{hi, lo};
+    }
+}
+
+// one block per segment: bitonic sort (descending) of the collected candidates, emit the first top_n
+__global__ __launch_bounds__(256) void k_sel_sort_emit(int G, int32_t n_real_total, int32_t top_n,
+                                                       const SelState *__restrict__ st,
+                                                       const SelCand *__restrict__ cand, int64_t *__restrict__ out_id,
+                                                       double *__restrict__ out_score, int32_t *__restrict__ out_counts)
+{
+    extern __shared__ SelCand sc[];
+    const int seg = blockIdx.x;
+    if (seg >= n_real_total) return;
+    int cnt = st[seg].cand_cnt;
+    if (cnt > SEL_SLOTS) cnt = SEL_SLOTS;
+    int N2 = 1;
+    while (N2 < cnt) N2 <<= 1;
+    const SelCand *c = cand + (size_t)seg * SEL_SLOTS;
+    for (int i = threadIdx.x; i < N2; i += blockDim.x) sc[i] = (i < cnt) ? c[i] : SelCand{0ull, 0ull};
+    __syncthreads();
+    for (int size = 2; size <= N2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < N2 / 2; t += blockDim.x) {
+                const int lo_i = 2 * t - (t & (stride - 1));
+                const int hi_i = lo_i + stride;
+                const bool desc = (lo_i & size) == 0;        // first half of each bitonic pair: descending
+                const SelCand a = sc[lo_i], b = sc[hi_i];
+                const bool a_lt_b = (a.hi < b.hi) || (a.hi == b.hi && a.lo < b.lo);
+                if (a_lt_b == desc) {
+                    sc[lo_i] = b;
+                    sc[hi_i] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int take = cnt < top_n ? cnt : top_n;
+    if (threadIdx.x == 0) out_counts[seg] = take;
+    for (int i = threadIdx.x; i < take; i += blockDim.x) {
+        const SelCand v = sc[i];
+        out_id[(size_t)seg * top_n + i] = (int64_t)(v.lo ^ 0x8000000000000000ull);
+        const uint64_t u = (v.hi & 0x8000000000000000ull) ? (v.hi ^ 0x8000000000000000ull) : ~v.hi;
+        double s;
+        __builtin_memcpy(&s, &u, 8);
+        out_score[(size_t)seg * top_n + i] = s;
+    }
+}
+
 #define RWR_DISPATCH_G(G, CALL)                          \
     switch (G) {                                         \
         case 1: { constexpr int GG = 1; CALL; } break;   \
@@ -103,5 +312,43 @@ int32_t rank_tile(rwr_graph *g, int G, int tile_in_group, int64_t first_seed_slo
     RWR_HIP(hipGetLastError());
     return RWR_OK;
 }
+
+// top-k for a whole tile group in one go (select path; top_n <= SEL_MAX_K)
+int32_t rank_group_select(rwr_graph *g, int G, int tg, int64_t first_seed_slot, int32_t n_real, int32_t top_n,
+                          const double *X, const int32_t *d_seeds, hipStream_t s)
+{
+    const int32_t m = g->n_items;
+    if (m == 0 || n_real <= 0) return RWR_OK;
+    const int nseg = tg * G;
+    const size_t st_bytes = (size_t)nseg * sizeof(SelState);
+    const size_t hist_bytes = (size_t)nseg * 256 * sizeof(uint32_t);
+    const size_t cand_bytes = (size_t)nseg * SEL_SLOTS * sizeof(SelCand);
+    RWR_TRY(g->sort_temp.ensure(st_bytes + hist_bytes + cand_bytes + 64));
+    SelState *st = (SelState *)g->sort_temp.p;
+    uint32_t *ghist = (uint32_t *)(g->sort_temp.p + st_bytes);
+    SelCand *cand = (SelCand *)(g->sort_temp.p + st_bytes + hist_bytes);
+    RWR_HIP(hipMemsetAsync(ghist, 0, hist_bytes, s));
+    hipLaunchKernelGGL(k_sel_init, dim3(cdiv((size_t)nseg, 64)), dim3(64), 0, s, nseg, top_n, d_seeds, st);
+    const unsigned nblk = cdiv((size_t)m, SEL_ROWS_PER_BLOCK);
+    for (int level = 0; level < SEL_LEVELS; ++level) {
+        RWR_DISPATCH_G(G, hipLaunchKernelGGL(k_sel_hist<GG>, dim3(nblk, tg), dim3(256), 0, s, g->n, m, g->item_rows.p,
+                                             g->node_id.p, X, st, ghist, level));
+        hipLaunchKernelGGL(k_sel_decide, dim3(cdiv((size_t)nseg, 64)), dim3(64), 0, s, nseg, st, ghist, level);
+    }
+    RWR_DISPATCH_G(G, hipLaunchKernelGGL(k_sel_collect<GG>, dim3(nblk, tg), dim3(256), 0, s, g->n, m, g->item_rows.p,
+                                         g->node_id.p, X, st, d_seeds, cand));
+    static const bool attr_ok = [] {
+        return hipFuncSetAttribute((const void *)k_sel_sort_emit, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   SEL_SLOTS * (int)sizeof(SelCand)) == hipSuccess;
+    }();
+    (void)attr_ok;
+    hipLaunchKernelGGL(k_sel_sort_emit, dim3(n_real), dim3(256), SEL_SLOTS * sizeof(SelCand), s, G, n_real, top_n, st,
+                       cand, g->d_out_id.p + (size_t)first_seed_slot * top_n,
+                       g->d_out_score.p + (size_t)first_seed_slot * top_n, g->d_counts.p + first_seed_slot);
+    RWR_HIP(hipGetLastError());
+    return RWR_OK;
+}
+
+int rank_select_max_k() { return SEL_MAX_K; }
 
 }  // namespace rwr

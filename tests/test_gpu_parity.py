@@ -165,3 +165,53 @@ def test_error_behaviour(amd):
     cnt = C.c_int64(0)
     st = lib.rwr_recommend(G._handle(), 0, C.c_float(0.5), 3, 0, None, None, C.byref(cnt))
     assert st == _lib.RWR_E_CAPACITY and cnt.value == 1
+
+
+@pytest.mark.parametrize("T", [0, 1, 2, 3])
+@pytest.mark.parametrize("top_n", [1, 50, 1024, 1025])
+def test_topk_select_ties_and_zeros(amd, T, top_n):
+    """Few iterations leave most items at score exactly 0: the k-th entry then sits inside a huge tie
+    that only the id (descending) breaks (Recommender.cs:36-37) -- the radix
+    select has to descend through all score digits into the id digits.  top_n = 1025 takes the
+    full-sort path instead; both must equal the oracle."""
+    g = gg.random_graph(31, n_users=300, n_items=4000, n_likes=5000, n_friend=100, n_mention=50)
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g)
+    seeds = np.array([0, 1, 5, 17, 33, 100, 299], dtype=np.int32)       # K not a multiple of the tile width
+    ids, sc, cnt = amd.Recommender(G).RecommendationBatch(seeds, 0.15, T, top_n)
+    oi, os_, oc = F.recommend_batch(seeds, 0.15, T, top_n)
+    assert (cnt == oc).all() and (ids == oi).all() and (bits(sc) == bits(os_)).all()
+
+
+def test_topk_more_than_candidates(amd):
+    g = gg.random_graph(32, n_users=50, n_items=40, n_likes=300)
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g)
+    seeds = np.arange(0, 50, dtype=np.int32)
+    ids, sc, cnt = amd.Recommender(G).RecommendationBatch(seeds, 0.15, 10, 64)     # only <= 40 items exist
+    oi, os_, oc = F.recommend_batch(seeds, 0.15, 10, 64)
+    assert (cnt == oc).all() and (cnt <= 40).all()
+    assert (ids == oi).all() and (bits(sc) == bits(os_)).all()
+
+
+def test_structural_ties_keep_id_order(amd):
+    """Items with identical in-neighbour sets get bitwise-equal scores; their order is id descending."""
+    n_users, n_items = 6, 40
+    node_id = np.concatenate([np.arange(6), 1000 + np.random.default_rng(3).permutation(n_items)]).astype(np.int64)
+    node_type = np.array([gg.NODE_USER] * n_users + [gg.NODE_ITEM] * n_items, dtype=np.uint8)
+    lists = {i: [] for i in range(n_users + n_items)}
+    for j in range(n_items):                     # every item liked by users 1 and 2 only -> all items symmetric
+        for u in (1, 2):
+            lists[u].append(n_users + j)
+            lists[n_users + j].append(u)
+    lists[0] = [n_users + 0]
+    lists[n_users + 0].append(0)
+    g = gg._from_lists(node_id, node_type, lists)
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g)
+    rec = amd.Recommender(G).Recommendation(1, 0.15, 6)
+    ids, sc = F.recommend(1, 0.15, 6)
+    assert [r[0] for r in rec] == ids.tolist() and (bits([r[1] for r in rec]) == bits(sc)).all()
+    bi, bs, bc = amd.Recommender(G).RecommendationBatch(np.array([1, 2, 0], dtype=np.int32), 0.15, 6, 10)
+    oi, os_, oc = F.recommend_batch(np.array([1, 2, 0], dtype=np.int32), 0.15, 6, 10)
+    assert (bi == oi).all() and (bits(bs) == bits(os_)).all() and (bc == oc).all()
