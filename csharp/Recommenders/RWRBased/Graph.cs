@@ -1,0 +1,77 @@
+// Drop-in replacement of Recommenders/RWRBased/Graph.cs of the reference: same public types, fields and
+// methods (Node, ForwardLink, Graph{nodes, edges, graph, buildGraph(), size()}), so TweetRecommender/*.cs
+// compile unchanged.  buildGraph() flattens the caller's dictionaries in list order and hands the RAW links
+// to librwr, which filters / normalises / transposes on the GPU.
+using System.Collections.Generic;
+
+namespace Recommenders.RWRBased {
+    public struct Node {
+        public long id;
+        public NodeType type;
+        public Node(long id) { this.id = id; this.type = NodeType.UNDEFINED; }
+        public Node(long id, NodeType type) { this.id = id; this.type = type; }
+    }
+
+    public struct ForwardLink {
+        public int targetNode;
+        public EdgeType type;
+        public double weight;
+        public ForwardLink(int targetNode, double weight) { this.targetNode = targetNode; this.type = EdgeType.UNDEFINED; this.weight = weight; }
+        public ForwardLink(int targetNode, EdgeType type, double weight) { this.targetNode = targetNode; this.type = type; this.weight = weight; }
+    }
+
+    public class Graph {
+        public Dictionary<int, Node> nodes;
+        public Dictionary<int, List<ForwardLink>> edges;
+        Dictionary<int, ForwardLink[]> normalized;        // materialised lazily from the device
+        internal GraphHandle handle;
+        long[] rowptr; int[] dst; byte[] etype;
+
+        public Graph(Dictionary<int, Node> nodes, Dictionary<int, List<ForwardLink>> edges) {
+            this.nodes = nodes;
+            this.edges = edges;
+        }
+
+        public void buildGraph() {
+            int n = nodes.Count;
+            var id = new long[n]; var type = new byte[n];
+            rowptr = new long[n + 1];
+            for (int i = 0; i < n; i++) {
+                id[i] = nodes[i].id; type[i] = (byte)nodes[i].type;
+                rowptr[i + 1] = rowptr[i] + (edges.ContainsKey(i) ? edges[i].Count : 0);
+            }
+            long m = rowptr[n];
+            dst = new int[m]; etype = new byte[m]; var w = new double[m];
+            long e = 0;
+            for (int i = 0; i < n; i++) {
+                if (!edges.ContainsKey(i)) continue;
+                foreach (ForwardLink l in edges[i]) { dst[e] = l.targetNode; etype[e] = (byte)l.type; w[e] = l.weight; e++; }
+            }
+            var opts = new RwrOpts { struct_size = 32, device = -1, mode = -1 };
+            Native.Check(Native.rwr_graph_create(n, id, type, rowptr, dst, etype, w, ref opts, out handle));
+            normalized = null;
+        }
+
+        // public field of the reference (Graph.cs:43), served as a property backed by the device copy
+        public Dictionary<int, ForwardLink[]> graph {
+            get {
+                if (normalized == null) {
+                    int n = nodes.Count;
+                    var wn = new double[System.Math.Max(1, dst.Length)]; var dg = new byte[n];
+                    Native.Check(Native.rwr_graph_get_normalized(handle, wn, dg));
+                    normalized = new Dictionary<int, ForwardLink[]>();
+                    for (int i = 0; i < n; i++) {
+                        if (dg[i] != 0) { normalized.Add(i, null); continue; }
+                        var list = new List<ForwardLink>();
+                        for (long p = rowptr[i]; p < rowptr[i + 1]; p++)
+                            if (etype[p] != 0) list.Add(new ForwardLink(dst[p], (EdgeType)etype[p], wn[p]));
+                        normalized.Add(i, list.ToArray());
+                    }
+                }
+                return normalized;
+            }
+        }
+
+        public int size() { return nodes.Count; }
+    }
+}

@@ -1,0 +1,48 @@
+// P/Invoke declarations of include/rwr.h.  Thin on purpose: every overload maps 1:1 onto a C entry point,
+// and recommendersystems_amd/_lib.py (ctypes) binds the very same signatures and IS exercised by the tests.
+// NOTE: there is no C# toolchain in the build image, so this shim is source only (INTEGRATION.md).
+using System;
+using System.Runtime.InteropServices;
+
+namespace Recommenders.RWRBased {
+    [StructLayout(LayoutKind.Sequential)]
+    internal struct RwrOpts {
+        public int struct_size, device, mode, tile_seeds, tile_group, profile;
+        public long workspace_bytes;
+    }
+
+    internal sealed class GraphHandle : SafeHandle {
+        // the reference types have no Dispose(): native memory is released by the finalizer of this SafeHandle
+        public GraphHandle() : base(IntPtr.Zero, true) { }
+        public override bool IsInvalid { get { return handle == IntPtr.Zero; } }
+        protected override bool ReleaseHandle() { Native.rwr_graph_destroy(handle); return true; }
+    }
+
+    internal static class Native {
+        const string Lib = "rwr";   // librwr.so
+        [DllImport(Lib)] public static extern IntPtr rwr_last_error();
+        [DllImport(Lib)] public static extern int rwr_device_count();
+        [DllImport(Lib)] public static extern int rwr_graph_create(int n, long[] node_id, byte[] node_type, long[] rowptr,
+            int[] dst, byte[] etype, double[] w, ref RwrOpts opts, out GraphHandle g);
+        [DllImport(Lib)] public static extern int rwr_graph_destroy(IntPtr g);
+        [DllImport(Lib)] public static extern int rwr_graph_get_normalized(GraphHandle g, double[] w_out, byte[] dangling_out);
+        [DllImport(Lib)] public static extern int rwr_recommend(GraphHandle g, int seed, float d, int n_iter, int top_n,
+            long[] out_id, double[] out_score, ref long inout_count);
+        [DllImport(Lib)] public static extern int rwr_recommend_batch(GraphHandle g, int[] seeds, int K, float d, int n_iter,
+            int top_n, long[] ids, double[] scores, int[] counts);
+        [DllImport(Lib)] public static extern int rwr_model_run(GraphHandle g, int seed, double d, int run_mode, double value,
+            double[] rank_out, out long iters_out);
+
+        public static void Check(int status) {
+            if (status == 0) return;
+            string msg = Marshal.PtrToStringAnsi(rwr_last_error());
+            switch (status) {
+                case 2: throw new ArgumentOutOfRangeException(msg);            // RWR_E_RANGE
+                case 1: throw new ArgumentException(msg);                      // RWR_E_INVALID
+                case 5: throw new OutOfMemoryException(msg);                   // RWR_E_NOMEM
+                case 7: throw new NotSupportedException(msg);                  // RWR_E_UNSUPPORTED
+                default: throw new InvalidOperationException(msg);             // no device / HIP error
+            }
+        }
+    }
+}
