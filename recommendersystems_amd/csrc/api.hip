@@ -121,8 +121,12 @@ int32_t rwr_graph_create(int32_t n, const int64_t *node_id, const uint8_t *node_
         set_error("device %d is %s; librwr is built for gfx950 only", g->device, prop.gcnArchName);
         return fail(RWR_E_NO_DEVICE);
     }
+    // the seed-row chain (stream2) is latency-bound and must not queue behind the SpMM's half-million
+    // workgroups: give its stream the highest dispatch priority
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&g->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&g->ev_a) != hipSuccess || hipEventCreate(&g->ev_b) != hipSuccess) {

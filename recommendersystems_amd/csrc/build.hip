@@ -237,6 +237,8 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     RWR_HIP(hipEventRecord(e1, s));
     RWR_HIP(hipStreamSynchronize(s));
     g->max_in_deg = h_flags[2];
+    g->h_in_ptr.resize((size_t)n + 1);
+    RWR_HIP(hipMemcpy(g->h_in_ptr.data(), g->in_ptr.p, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost));
     float ms = 0.f;
     RWR_HIP(hipEventElapsedTime(&ms, e0, e1));
     g->stats.build_ms = ms;

@@ -22,6 +22,7 @@ struct rwr_graph {
     rwr::DevBuf<uint8_t> etype;
     rwr::DevBuf<double> w_norm_raw;   // Graph.graph weights per raw link (0 for UNDEFINED)
     std::vector<int64_t> h_rowptr;    // host copy (seed validation, exclusion sizing)
+    std::vector<int64_t> h_in_ptr;    // host copy of in_ptr (sizing of the seeds' in-link term buffers)
     // transposed (in-neighbour) CSR of the normalised matrix, entries ordered
     // (source asc, list position asc) = addend order of Model.deliverRanks
     rwr::DevBuf<int64_t> in_ptr;
@@ -36,7 +37,10 @@ struct rwr_graph {
     // batch workspace (lazily sized)
     rwr::DevBuf<double> X, Y;         // rank matrices [tile][n][G]
     rwr::DevBuf<int32_t> d_seeds;     // [tile][G], -1 = padding lane
+    rwr::DevBuf<int32_t> d_slot_k;    // [tile][G]: batch position of the seed in this slot (-1 = padding)
     rwr::DevBuf<double> d_part;       // fast mode: restart partial sums
+    rwr::DevBuf<int64_t> d_evoff;     // exact mode: per seed slot, offset of its in-link terms in d_evterm
+    rwr::DevBuf<double> d_evterm;     // exact mode: ((1-d) x_src) * w of every link INTO a seed, list order
     rwr::DevBuf<uint64_t> keys, keys_alt;
     rwr::DevBuf<uint32_t> vals, vals_alt;
     rwr::DevBuf<uint8_t> sort_temp;

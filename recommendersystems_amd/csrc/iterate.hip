@@ -22,6 +22,7 @@
 // with -ffp-contract=off).
 #include "engine.h"
 
+#include <algorithm>
 #include <chrono>
 #include <climits>
 #include <cstdlib>
@@ -203,6 +204,28 @@ __global__ __launch_bounds__(64) void k_seed_chain(int32_t n, int ntiles, const 
     Y[(size_t)tile * (size_t)n * G + (size_t)s * G + k] = acc;
 }
 
+// EXACT mode helper: the addends of the links INTO each seed, ((1-d) x_src) * w in list order
+// (Model.cs:84,87 for target == seed), computed in parallel ahead of the sequential fold.
+template <int G>
+__global__ __launch_bounds__(256) void k_seed_terms(int32_t n, const int64_t *__restrict__ in_ptr,
+                                                    const int32_t *__restrict__ in_src,
+                                                    const double *__restrict__ in_w, const double *__restrict__ X,
+                                                    const int32_t *__restrict__ seeds, double c1,
+                                                    const int64_t *__restrict__ evoff, double *__restrict__ evterm)
+{
+    const int slot = blockIdx.y;                 // tile * G + k
+    const int32_t s = seeds[slot];
+    if (s < 0) return;
+    const int tile = slot / G, k = slot % G;
+    const double *x = X + (size_t)tile * (size_t)n * G + k;
+    const int64_t p0 = in_ptr[s], deg = in_ptr[s + 1] - p0;
+    double *out = evterm + evoff[slot];
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < deg; q += (int64_t)gridDim.x * blockDim.x) {
+        const double rw = c1 * x[(size_t)in_src[p0 + q] * G];
+        out[q] = rw * in_w[p0 + q];
+    }
+}
+
 // EXACT mode, pipelined form of k_seed_chain: one 256-thread workgroup per tile.
 // All four waves stream the tile's rank matrix in 64 KiB chunks (coalesced, 32 loads in
 // flight per lane), turn each value into its restart addend
@@ -214,16 +237,19 @@ __global__ __launch_bounds__(64) void k_seed_chain(int32_t n, int ntiles, const 
 // path, which interleaves that link's addend before the node's restart addend exactly
 // as Model.cs:85-93 does.
 constexpr int CHAIN_CE = 8192;                 // doubles per chunk (64 KiB)
-constexpr int CHAIN_LPT = CHAIN_CE / 256;      // loads per thread per chunk
-template <int G>
-__global__ __launch_bounds__(256) void k_seed_chain_lds(int32_t n, const int64_t *__restrict__ in_ptr,
-                                                        const int32_t *__restrict__ in_src,
-                                                        const double *__restrict__ in_w,
-                                                        const uint8_t *__restrict__ dangling,
-                                                        const double *__restrict__ X, double *__restrict__ Y,
-                                                        const int32_t *__restrict__ seeds, double c1)
+template <int G, int NT, int NPF>
+__global__ __launch_bounds__(NT) void k_seed_chain_lds(int32_t n, const int64_t *__restrict__ in_ptr,
+                                                       const int32_t *__restrict__ in_src,
+                                                       const double *__restrict__ in_w,
+                                                       const uint8_t *__restrict__ dangling,
+                                                       const double *__restrict__ X, double *__restrict__ Y,
+                                                       const int32_t *__restrict__ seeds, double c1,
+                                                       const int64_t *__restrict__ evoff,
+                                                       const double *__restrict__ evterm, int dbg)
 {
+    // NT threads stage, NPF chunks are kept in flight in registers ahead of the one being folded
     constexpr int CR = CHAIN_CE / G;           // rows per chunk
+    constexpr int LPT = CHAIN_CE / NT;         // loads per thread per chunk
     extern __shared__ double chain_buf[];      // [2][CHAIN_CE]
     const int tile = blockIdx.x;
     const double *x = X + (size_t)tile * (size_t)n * G;
@@ -234,80 +260,120 @@ __global__ __launch_bounds__(256) void k_seed_chain_lds(int32_t n, const int64_t
     // consumer state (meaningful in wave 0, lanes < G)
     const bool consumer = tid < G;
     const int k = tid % G;
+    // Links INTO the seed: their addends ((1-d) x_src) * w were computed by k_seed_terms (list order).
+    // The lane keeps the current link (nxt, tcur) and the following one (nxt2, tcur2) in registers so
+    // that taking a link never waits on memory unless two links of one seed are a few rows apart.
     int32_t s = -1;
-    int64_t p = 0, e = 0;
-    int32_t nxt = INT_MAX;
+    int64_t p = 0, e = 0;            // p = index of the link AFTER (nxt2, tcur2)
+    const int32_t *srcp = in_src;
+    const double *termp = evterm;
+    int32_t nxt = INT_MAX, raw_s = INT_MAX;
+    double tcur = 0.0, raw_t = 0.0;
+    bool has2 = false;
     if (consumer) {
         s = seeds[tile * G + k];
         if (s >= 0) {
             p = in_ptr[s];
             e = in_ptr[s + 1];
-            nxt = (p < e) ? in_src[p] : INT_MAX;
+            termp = evterm + evoff[tile * G + k] - p;      // termp[link index] = term of that link
+            if (p < e) { nxt = srcp[p]; tcur = termp[p]; ++p; }
+            if (p < e) { raw_s = srcp[p]; raw_t = termp[p]; has2 = true; ++p; }
         }
     }
     double acc = 0.0;
 
-    // branch-free, clamped loads so that all 2*CHAIN_LPT loads of a chunk are in flight together
-    double reg[CHAIN_LPT];
-    uint8_t dreg[CHAIN_LPT];
-    auto load_chunk = [&](int c) {
-        const int64_t base = (int64_t)c * CHAIN_CE;
-#pragma unroll
-        for (int q = 0; q < CHAIN_LPT; ++q) {
-            int64_t el = base + (int64_t)q * 256 + tid;
-            el = el < total ? el : total - 1;
-            reg[q] = x[el];
-            dreg[q] = dangling[el / G];
-        }
-    };
-    auto stage_chunk = [&](int c) {
-        const int64_t base = (int64_t)c * CHAIN_CE;
-        double *buf = chain_buf + (size_t)(c & 1) * CHAIN_CE;
-#pragma unroll
-        for (int q = 0; q < CHAIN_LPT; ++q) {
-            const int off = q * 256 + tid;
-            const double xv = (base + off < total) ? reg[q] : 0.0;   // past the end: +0.0, changes nothing
-            const double rw = c1 * xv;
-            buf[off] = dreg[q] ? xv : (xv - rw);
-        }
-    };
-
-    load_chunk(0);
-    for (int c = 0; c < nchunks; ++c) {
-        stage_chunk(c);
-        if (c + 1 < nchunks) load_chunk(c + 1);
-        __syncthreads();
-        if (tid < WAVE) {   // wave 0 folds chunk c
-            const double *buf = chain_buf + (size_t)(c & 1) * CHAIN_CE;
-            const int64_t row0 = (int64_t)c * CR;
-            // 16-row sub-blocks: the common one has no link into any seed of the tile and is a pure
-            // add chain; the rare one checks every row (per-lane) for pending in-links
-            for (int r0 = 0; r0 < CR; r0 += 16) {
-                double v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = buf[(r0 + u) * G + k];
-                const bool evt = __any(consumer && nxt < row0 + r0 + 16);
-                if (!evt) {
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) acc += v[u];
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int64_t i = row0 + r0 + u;
-                        while (consumer && nxt == i) {           // links i -> seed come first (Model.cs:85-88)
-                            const double rw = c1 * x[(size_t)i * G + k];
-                            acc += rw * in_w[p];
-                            ++p;
-                            nxt = (p < e) ? in_src[p] : INT_MAX;
-                        }
-                        acc += v[u];                             // then the restart addend (Model.cs:91-93,96-97)
-                    }
-                }
-            }
-        }
-        // no second barrier: chunk c+2 is staged into this buffer only after every wave has passed
-        // the barrier of phase c+1, which wave 0 reaches after finishing this fold
+    // branch-free, clamped loads so that all loads of a chunk are in flight together
+    double reg[NPF][LPT];
+    uint8_t dreg[NPF][LPT];
+#define CHAIN_LOAD(SLOT, C)                                                \
+    {                                                                      \
+        const int64_t base__ = (int64_t)(C) * CHAIN_CE;                    \
+        _Pragma("unroll") for (int q = 0; q < LPT; ++q) {                  \
+            int64_t el = base__ + (int64_t)q * NT + tid;                   \
+            el = el < total ? el : total - 1;                              \
+            reg[SLOT][q] = x[el];                                          \
+            dreg[SLOT][q] = dangling[el / G];                              \
+        }                                                                  \
     }
+#define CHAIN_STAGE(SLOT, C)                                                                          \
+    {                                                                                                 \
+        const int64_t base__ = (int64_t)(C) * CHAIN_CE;                                               \
+        double *buf__ = chain_buf + (size_t)((C) & 1) * CHAIN_CE;                                     \
+        _Pragma("unroll") for (int q = 0; q < LPT; ++q) {                                             \
+            const int off = q * NT + tid;                                                             \
+            const double xv = (base__ + off < total) ? reg[SLOT][q] : 0.0; /* past the end: +0.0 */   \
+            const double rw = c1 * xv;                                                                \
+            buf__[off] = dreg[SLOT][q] ? xv : (xv - rw);                                              \
+        }                                                                                             \
+    }
+
+#pragma unroll
+    for (int ph = 0; ph < NPF; ++ph)
+        if (ph < nchunks) CHAIN_LOAD(ph, ph);
+    for (int c0 = 0; c0 < nchunks; c0 += NPF) {
+#pragma unroll
+        for (int ph = 0; ph < NPF; ++ph) {
+            const int c = c0 + ph;
+            if (c >= nchunks) break;                       // block-uniform
+            if (!(dbg & 2)) {
+                CHAIN_STAGE(ph, c);
+                if (c + NPF < nchunks) CHAIN_LOAD(ph, c + NPF);
+            }
+            // LDS-only barrier: __syncthreads() would also drain vmcnt and expose the latency of the
+            // prefetch loads just issued; only the staged LDS writes have to be complete here
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            if (tid < WAVE && !(dbg & 1)) {   // wave 0 folds chunk c
+                const double *buf = chain_buf + (size_t)(c & 1) * CHAIN_CE;
+                const int64_t row0 = (int64_t)c * CR;
+                // 16-row sub-blocks, software-pipelined: the LDS reads of the next sub-block are issued
+                // before the dependent adds of the current one.  The common sub-block has no link into any
+                // seed of the tile and is a pure add chain; the rare one checks every row (per lane).
+                __builtin_amdgcn_s_setprio(3);
+                double va[16], vb[16];
+#define CHAIN_READ(V, R0) _Pragma("unroll") for (int u = 0; u < 16; ++u) V[u] = buf[((R0) + u) * G + k];
+#define CHAIN_FOLD(V, R0)                                                                              \
+    {                                                                                                  \
+        const bool evt = __any(consumer && nxt < row0 + (R0) + 16);                                    \
+        if (!evt) {                                                                                    \
+            _Pragma("unroll") for (int u = 0; u < 16; ++u) acc += V[u];                                \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                           \
+                const int64_t i = row0 + (R0) + u;                                                     \
+                while (consumer && nxt == i) { /* links i -> seed come first (Model.cs:85-88) */       \
+                    acc += tcur;                                                                       \
+                    /* promote the pending link (its loads were issued at the previous take) ... */    \
+                    nxt = has2 ? raw_s : INT_MAX;                                                      \
+                    tcur = raw_t;                                                                      \
+                    /* ... and issue the loads of the one after it; they are not touched until then */ \
+                    has2 = p < e;                                                                      \
+                    const int64_t pc = has2 ? p : e - 1;                                               \
+                    raw_s = srcp[pc];                                                                  \
+                    raw_t = termp[pc];                                                                 \
+                    p += has2 ? 1 : 0;                                                                 \
+                }                                                                                      \
+                acc += V[u]; /* then the restart addend (Model.cs:91-93,96-97) */                      \
+            }                                                                                          \
+        }                                                                                              \
+    }
+                CHAIN_READ(va, 0)
+                for (int r0 = 0; r0 < CR; r0 += 32) {
+                    CHAIN_READ(vb, r0 + 16)
+                    CHAIN_FOLD(va, r0)
+                    if (r0 + 32 < CR) CHAIN_READ(va, r0 + 32)
+                    CHAIN_FOLD(vb, r0 + 16)
+                }
+#undef CHAIN_READ
+#undef CHAIN_FOLD
+                __builtin_amdgcn_s_setprio(0);
+            }
+            // no second barrier: chunk c+2 is staged into this buffer only after every wave has passed
+            // the barrier of phase c+1, which wave 0 reaches after finishing this fold
+        }
+    }
+#undef CHAIN_LOAD
+#undef CHAIN_STAGE
     if (consumer && s >= 0) Y[(size_t)tile * (size_t)n * G + (size_t)s * G + k] = acc;
 }
 
@@ -406,19 +472,31 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
 }
 template <int G>
 static void launch_chain(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
-                         hipStream_t s)
+                         const int64_t *evoff, hipStream_t s)
 {
+    const unsigned term_blocks = g->max_in_deg > 256 * 8 ? 8u : cdiv((size_t)(g->max_in_deg > 0 ? g->max_in_deg : 1), 256);
     static const int variant = [] { const char *e = getenv("RWR_CHAIN"); return e ? atoi(e) : 1; }();
-    if (variant == 1) {
-        static const bool attr_ok = [] {
-            return hipFuncSetAttribute((const void *)k_seed_chain_lds<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * CHAIN_CE * (int)sizeof(double)) == hipSuccess;
-        }();
-        (void)attr_ok;
-        hipLaunchKernelGGL(k_seed_chain_lds<G>, dim3(tg), dim3(256), 2 * CHAIN_CE * sizeof(double), s, g->n,
-                           g->in_ptr.p, g->in_src.p, g->in_w.p, g->dangling.p, X, Y, seeds, c1);
-        return;
+    static const int dbg = [] { const char *e = getenv("RWR_CHAIN_DBG"); return e ? atoi(e) : 0; }();
+#define RWR_CHAIN_LAUNCH(NT, NPF)                                                                                  \
+    {                                                                                                              \
+        static const bool attr_ok = [] {                                                                           \
+            return hipFuncSetAttribute((const void *)k_seed_chain_lds<G, NT, NPF>,                                 \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,                                 \
+                                       2 * CHAIN_CE * (int)sizeof(double)) == hipSuccess;                          \
+        }();                                                                                                       \
+        (void)attr_ok;                                                                                             \
+        hipLaunchKernelGGL(k_seed_terms<G>, dim3(term_blocks, tg * G), dim3(256), 0, s, g->n, g->in_ptr.p,          \
+                           g->in_src.p, g->in_w.p, X, seeds, c1, evoff, g->d_evterm.p);                            \
+        hipLaunchKernelGGL((k_seed_chain_lds<G, NT, NPF>), dim3(tg), dim3(NT), 2 * CHAIN_CE * sizeof(double), s,   \
+                           g->n, g->in_ptr.p, g->in_src.p, g->in_w.p, g->dangling.p, X, Y, seeds, c1, evoff,       \
+                           g->d_evterm.p, dbg);                                                                    \
+        return;                                                                                                    \
     }
+    if (variant == 1) RWR_CHAIN_LAUNCH(256, 1)
+    if (variant == 2) RWR_CHAIN_LAUNCH(512, 2)
+    if (variant == 3) RWR_CHAIN_LAUNCH(1024, 4)
+    if (variant == 4) RWR_CHAIN_LAUNCH(256, 2)
+#undef RWR_CHAIN_LAUNCH
     hipLaunchKernelGGL(k_seed_chain<G>, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, g->n, tg, g->in_ptr.p,
                        g->in_src.p, g->in_w.p, g->dangling.p, X, Y, seeds, c1);
 }
@@ -466,11 +544,11 @@ struct EvPool {
 };
 
 // declared in rank.hip
-int32_t rank_group_select(rwr_graph *g, int G, int tg, int64_t first_seed_slot, int32_t n_real, int32_t top_n,
-                          const double *X, const int32_t *d_seeds, hipStream_t s);
+int32_t rank_group_select(rwr_graph *g, int G, int tg, const int32_t *d_slot_k, int32_t top_n, const double *X,
+                          const int32_t *d_seeds, hipStream_t s);
 int rank_select_max_k();
-int32_t rank_tile(rwr_graph *g, int G, int tile_in_group, int64_t first_seed_slot, int32_t n_real, int32_t top_n,
-                  const double *X, const int32_t *d_seeds_tile, hipStream_t s);
+int32_t rank_tile(rwr_graph *g, int G, const int32_t *d_slot_k_tile, int32_t top_n, const double *X,
+                  const int32_t *d_seeds_tile, hipStream_t s);
 
 static int resolve_G(const rwr_graph *g, int32_t K)
 {
@@ -481,8 +559,8 @@ static int resolve_G(const rwr_graph *g, int32_t K)
     return want;
 }
 
-int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, double d, int64_t n_iter,
-                      double **final_X, EvPool &pool, std::vector<hipEvent_t> &spmm_ev,
+int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, const int64_t *d_evoff, double d,
+                      int64_t n_iter, double **final_X, EvPool &pool, std::vector<hipEvent_t> &spmm_ev,
                       std::vector<hipEvent_t> &chain_ev)
 {
     const int32_t n = g->n;
@@ -495,13 +573,15 @@ int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, doubl
     RWR_HIP(hipMemsetAsync(X, 0, elems * sizeof(double), s));
     hipLaunchKernelGGL(k_init_seeds, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, X, d_seeds);
     for (int64_t it = 0; it < n_iter; ++it) {
+        static const int serial = [] { const char *e = getenv("RWR_CHAIN_SERIAL"); return e ? atoi(e) : 0; }();
+        if (exact && serial) s2 = s;
         if (exact) {
             // fork: the seed-row chain runs beside the SpMM on the second stream
             RWR_HIP(hipEventRecord(g->ev_fork, s));
-            RWR_HIP(hipStreamWaitEvent(s2, g->ev_fork, 0));
+            if (s2 != s) RWR_HIP(hipStreamWaitEvent(s2, g->ev_fork, 0));
             hipEvent_t c0 = nullptr, c1e = nullptr;
             if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, s2)); }
-            RWR_DISPATCH_G(G, launch_chain<GG>(g, tg, X, Y, d_seeds, c1, s2));
+            RWR_DISPATCH_G(G, launch_chain<GG>(g, tg, X, Y, d_seeds, c1, d_evoff, s2));
             if (prof) { RWR_HIP(hipEventRecord(c1e, s2)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
             RWR_HIP(hipEventRecord(g->ev_join, s2));
         } else {
@@ -515,7 +595,7 @@ int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, doubl
         RWR_DISPATCH_G(G, launch_spmm<GG>(g, tg, X, Y, d_seeds, c1, exact ? 1 : 0, s));
         if (prof) { RWR_HIP(hipEventRecord(b, s)); spmm_ev.push_back(a); spmm_ev.push_back(b); }
         if (exact) {
-            RWR_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
+            if (s2 != s) RWR_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
         } else {
             RWR_DISPATCH_G(G, launch_restart_final<GG>(g, tg, Y, d_seeds, s));
         }
@@ -544,12 +624,46 @@ static int32_t ensure_workspace(rwr_graph *g, int G, int32_t K, int *TG_out)
     int TG = g->opts.tile_group > 0 ? g->opts.tile_group : (int)(cap / (per_tile ? per_tile : 1));
     if (TG < 1) TG = 1;
     if (TG > ntiles) TG = ntiles;
-    if (TG > 65535) TG = 65535;
+    if (TG > 65535 / G) TG = 65535 / G;   // grid.y of the per-slot kernels is TG * G
     RWR_TRY(g->X.ensure((size_t)TG * n * G));
     RWR_TRY(g->Y.ensure((size_t)TG * n * G));
     RWR_TRY(g->d_seeds.ensure((size_t)ntiles * G));
     RWR_TRY(g->d_part.ensure((size_t)TG * RP_GRID * G));
     *TG_out = TG;
+    return RWR_OK;
+}
+
+// Seeds are dealt to tile slots by in-degree rank, round-robin over the tiles, so that the links INTO the
+// seeds (the only non-streaming work of the exact seed-row kernel) spread evenly over the tiles instead of
+// piling up in the tile that would hold the batch's hottest seeds.  slot_k maps a slot back to the
+// caller's batch position; padding slots hold seed -1.  Also: offsets of every slot's in-link term list.
+static int32_t upload_seed_slots(rwr_graph *g, const int32_t *seeds, int32_t K, int G, std::vector<int32_t> *slot_k_out)
+{
+    const int ntiles = (int)cdiv((size_t)K, (size_t)G);
+    const size_t slots = (size_t)ntiles * G;
+    std::vector<int32_t> hs(slots, -1), sk(slots, -1);
+    std::vector<int64_t> off(slots + 1, 0);
+    std::vector<int32_t> order(K);
+    for (int32_t k = 0; k < K; ++k) order[k] = k;
+    auto indeg = [&](int32_t k) { return g->h_in_ptr[seeds[k] + 1] - g->h_in_ptr[seeds[k]]; };
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return indeg(a) > indeg(b); });
+    for (int32_t r = 0; r < K; ++r) {
+        const size_t slot = (size_t)(r % ntiles) * G + (size_t)(r / ntiles);
+        hs[slot] = seeds[order[r]];
+        sk[slot] = order[r];
+    }
+    for (size_t q = 0; q < slots; ++q) {
+        int64_t deg = hs[q] >= 0 ? g->h_in_ptr[hs[q] + 1] - g->h_in_ptr[hs[q]] : 0;
+        off[q + 1] = off[q] + deg;
+    }
+    RWR_TRY(g->d_seeds.ensure(slots));
+    RWR_TRY(g->d_slot_k.ensure(slots));
+    RWR_TRY(g->d_evoff.ensure(slots + 1));
+    RWR_TRY(g->d_evterm.ensure((size_t)off[slots] + 1));
+    RWR_HIP(hipMemcpy(g->d_seeds.p, hs.data(), slots * sizeof(int32_t), hipMemcpyHostToDevice));
+    RWR_HIP(hipMemcpy(g->d_slot_k.p, sk.data(), slots * sizeof(int32_t), hipMemcpyHostToDevice));
+    RWR_HIP(hipMemcpy(g->d_evoff.p, off.data(), (slots + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (slot_k_out) *slot_k_out = sk;
     return RWR_OK;
 }
 
@@ -585,9 +699,8 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
     RWR_TRY(ensure_workspace(g, G, K, &TG));
     const int ntiles = (int)cdiv((size_t)K, (size_t)G);
     hipStream_t s = g->stream;
-    std::vector<int32_t> hs((size_t)ntiles * G, -1);
-    for (int32_t k = 0; k < K; ++k) hs[k] = seeds[k];
-    RWR_HIP(hipMemcpy(g->d_seeds.p, hs.data(), hs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    std::vector<int32_t> slot_k;
+    RWR_TRY(upload_seed_slots(g, seeds, K, G, &slot_k));
     const size_t out_elems = (size_t)ntiles * G * (size_t)top_n;
     RWR_TRY(g->d_out_id.ensure(out_elems));
     RWR_TRY(g->d_out_score.ensure(out_elems));
@@ -605,10 +718,10 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
         double *Xf = nullptr;
         hipEvent_t i0 = nullptr, i1 = nullptr;
         if (prof) { i0 = pool.get(); i1 = pool.get(); RWR_HIP(hipEventRecord(i0, s)); }
-        RWR_TRY(iterate_group(g, G, tg, dseeds, d, n_iter, &Xf, pool, spmm_ev, chain_ev));
+        RWR_TRY(iterate_group(g, G, tg, dseeds, g->d_evoff.p + (size_t)t0 * G, d, n_iter, &Xf, pool, spmm_ev, chain_ev));
         if (prof) { RWR_HIP(hipEventRecord(i1, s)); iter_ev.push_back(i0); iter_ev.push_back(i1); }
-        int32_t real = K - t0 * G;
-        if (real > tg * G) real = tg * G;
+        int32_t real = 0;
+        for (size_t q = (size_t)t0 * G; q < (size_t)(t0 + tg) * G; ++q) real += slot_k[q] >= 0;
         g->stats.spmm_seed_steps += (int64_t)real * n_iter;
         hipEvent_t a = nullptr, b = nullptr;
         if (prof) { a = pool.get(); b = pool.get(); RWR_HIP(hipEventRecord(a, s)); }
@@ -617,12 +730,10 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
         RWR_HIP(hipGetLastError());
         static const int force_sort = [] { const char *e = getenv("RWR_RANK_SORT"); return e ? atoi(e) : 0; }();
         if (top_n <= rank_select_max_k() && !force_sort) {
-            RWR_TRY(rank_group_select(g, G, tg, (int64_t)t0 * G, real, top_n, Xf, dseeds, s));
+            RWR_TRY(rank_group_select(g, G, tg, g->d_slot_k.p + (size_t)t0 * G, top_n, Xf, dseeds, s));
         } else {
             for (int t = 0; t < tg; ++t) {
-                int32_t n_real = K - (t0 + t) * G;
-                if (n_real > G) n_real = G;
-                RWR_TRY(rank_tile(g, G, t, (int64_t)(t0 + t) * G, n_real, top_n, Xf + (size_t)t * (size_t)n * G,
+                RWR_TRY(rank_tile(g, G, g->d_slot_k.p + (size_t)(t0 + t) * G, top_n, Xf + (size_t)t * (size_t)n * G,
                                   dseeds + (size_t)t * G, s));
             }
         }
@@ -663,11 +774,11 @@ int32_t model_run_iters(rwr_graph *g, int32_t seed, double d, int64_t n_iter, do
     const int G = 1;
     int TG = 1;
     RWR_TRY(ensure_workspace(g, G, 1, &TG));
-    RWR_HIP(hipMemcpy(g->d_seeds.p, &seed, sizeof(int32_t), hipMemcpyHostToDevice));
     EvPool pool;
     std::vector<hipEvent_t> a, b;
     double *Xf = nullptr;
-    RWR_TRY(iterate_group(g, G, 1, g->d_seeds.p, d, n_iter, &Xf, pool, a, b));
+    RWR_TRY(upload_seed_slots(g, &seed, 1, 1, nullptr));
+    RWR_TRY(iterate_group(g, G, 1, g->d_seeds.p, g->d_evoff.p, d, n_iter, &Xf, pool, a, b));
     RWR_HIP(hipMemcpyAsync(rank_out, Xf, sizeof(double) * n, hipMemcpyDeviceToHost, g->stream));
     RWR_HIP(hipStreamSynchronize(g->stream));
     RWR_HIP(hipStreamSynchronize(g->stream2));

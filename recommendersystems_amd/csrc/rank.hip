@@ -43,8 +43,8 @@ __global__ void k_rank_count(int32_t n_items, int G, const uint64_t *__restrict_
     counts[k] = lo;
 }
 
-__global__ __launch_bounds__(256) void k_rank_emit(int32_t n_items, int G, int32_t n_real, int32_t top_n,
-                                                   const uint32_t *__restrict__ vals,
+__global__ __launch_bounds__(256) void k_rank_emit(int32_t n_items, int G, const int32_t *__restrict__ slot_k,
+                                                   int32_t top_n, const uint32_t *__restrict__ vals,
                                                    const int32_t *__restrict__ cand_counts,
                                                    const int32_t *__restrict__ item_order,
                                                    const int64_t *__restrict__ node_id,
@@ -52,15 +52,16 @@ __global__ __launch_bounds__(256) void k_rank_emit(int32_t n_items, int G, int32
                                                    double *__restrict__ out_score, int32_t *__restrict__ out_counts)
 {
     const int k = blockIdx.y;
-    if (k >= n_real) return;
+    const int32_t orow = slot_k[k];              // batch position of this slot's seed
+    if (orow < 0) return;
     int32_t cnt = cand_counts[k];
     if (cnt > top_n) cnt = top_n;
     const int32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q == 0) out_counts[k] = cnt;
+    if (q == 0) out_counts[orow] = cnt;
     if (q >= cnt) return;
     const int32_t row = item_order[vals[(size_t)k * n_items + q]];
-    out_id[(size_t)k * top_n + q] = node_id[row];
-    out_score[(size_t)k * top_n + q] = X[(size_t)row * G + k];
+    out_id[(size_t)orow * top_n + q] = node_id[row];
+    out_score[(size_t)orow * top_n + q] = X[(size_t)row * G + k];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -229,14 +230,15 @@ __global__ __launch_bounds__(256) void k_sel_collect(int32_t n, int32_t n_items,
 }
 
 // one block per segment: bitonic sort (descending) of the collected candidates, emit the first top_n
-__global__ __launch_bounds__(256) void k_sel_sort_emit(int G, int32_t n_real_total, int32_t top_n,
+__global__ __launch_bounds__(256) void k_sel_sort_emit(const int32_t *__restrict__ slot_k, int32_t top_n,
                                                        const SelState *__restrict__ st,
                                                        const SelCand *__restrict__ cand, int64_t *__restrict__ out_id,
                                                        double *__restrict__ out_score, int32_t *__restrict__ out_counts)
 {
     extern __shared__ SelCand sc[];
     const int seg = blockIdx.x;
-    if (seg >= n_real_total) return;
+    const int32_t orow = slot_k[seg];            // batch position of this slot's seed
+    if (orow < 0) return;
     int cnt = st[seg].cand_cnt;
     if (cnt > SEL_SLOTS) cnt = SEL_SLOTS;
     int N2 = 1;
@@ -261,14 +263,14 @@ __global__ __launch_bounds__(256) void k_sel_sort_emit(int G, int32_t n_real_tot
         }
     }
     int take = cnt < top_n ? cnt : top_n;
-    if (threadIdx.x == 0) out_counts[seg] = take;
+    if (threadIdx.x == 0) out_counts[orow] = take;
     for (int i = threadIdx.x; i < take; i += blockDim.x) {
         const SelCand v = sc[i];
-        out_id[(size_t)seg * top_n + i] = (int64_t)(v.lo ^ 0x8000000000000000ull);
+        out_id[(size_t)orow * top_n + i] = (int64_t)(v.lo ^ 0x8000000000000000ull);
         const uint64_t u = (v.hi & 0x8000000000000000ull) ? (v.hi ^ 0x8000000000000000ull) : ~v.hi;
         double s;
         __builtin_memcpy(&s, &u, 8);
-        out_score[(size_t)seg * top_n + i] = s;
+        out_score[(size_t)orow * top_n + i] = s;
     }
 }
 
@@ -283,12 +285,11 @@ __global__ __launch_bounds__(256) void k_sel_sort_emit(int G, int32_t n_real_tot
         default: { constexpr int GG = 64; CALL; } break; \
     }
 
-int32_t rank_tile(rwr_graph *g, int G, int tile_in_group, int64_t first_seed_slot, int32_t n_real, int32_t top_n,
-                  const double *X, const int32_t *d_seeds_tile, hipStream_t s)
+int32_t rank_tile(rwr_graph *g, int G, const int32_t *d_slot_k_tile, int32_t top_n, const double *X,
+                  const int32_t *d_seeds_tile, hipStream_t s)
 {
-    (void)tile_in_group;
     const int32_t m = g->n_items;
-    if (m == 0 || n_real <= 0) return RWR_OK;
+    if (m == 0) return RWR_OK;
     const size_t tot = (size_t)G * m;
     RWR_TRY(g->keys.ensure(tot));
     RWR_TRY(g->keys_alt.ensure(tot));
@@ -306,19 +307,18 @@ int32_t rank_tile(rwr_graph *g, int G, int tile_in_group, int64_t first_seed_slo
     int32_t *cand = (int32_t *)(g->sort_temp.p + radix_sort_temp_bytes((size_t)m, G));
     hipLaunchKernelGGL(k_rank_count, dim3(1), dim3(64), 0, s, m, G, ks, cand);
     int32_t width = top_n < m ? top_n : m;
-    hipLaunchKernelGGL(k_rank_emit, dim3(cdiv((size_t)width, 256), n_real), dim3(256), 0, s, m, G, n_real, top_n, vs,
-                       cand, g->item_order.p, g->node_id.p, X, g->d_out_id.p + (size_t)first_seed_slot * top_n,
-                       g->d_out_score.p + (size_t)first_seed_slot * top_n, g->d_counts.p + first_seed_slot);
+    hipLaunchKernelGGL(k_rank_emit, dim3(cdiv((size_t)width, 256), G), dim3(256), 0, s, m, G, d_slot_k_tile, top_n, vs,
+                       cand, g->item_order.p, g->node_id.p, X, g->d_out_id.p, g->d_out_score.p, g->d_counts.p);
     RWR_HIP(hipGetLastError());
     return RWR_OK;
 }
 
 // top-k for a whole tile group in one go (select path; top_n <= SEL_MAX_K)
-int32_t rank_group_select(rwr_graph *g, int G, int tg, int64_t first_seed_slot, int32_t n_real, int32_t top_n,
-                          const double *X, const int32_t *d_seeds, hipStream_t s)
+int32_t rank_group_select(rwr_graph *g, int G, int tg, const int32_t *d_slot_k, int32_t top_n, const double *X,
+                          const int32_t *d_seeds, hipStream_t s)
 {
     const int32_t m = g->n_items;
-    if (m == 0 || n_real <= 0) return RWR_OK;
+    if (m == 0) return RWR_OK;
     const int nseg = tg * G;
     const size_t st_bytes = (size_t)nseg * sizeof(SelState);
     const size_t hist_bytes = (size_t)nseg * 256 * sizeof(uint32_t);
@@ -342,9 +342,8 @@ int32_t rank_group_select(rwr_graph *g, int G, int tg, int64_t first_seed_slot, 
                                    SEL_SLOTS * (int)sizeof(SelCand)) == hipSuccess;
     }();
     (void)attr_ok;
-    hipLaunchKernelGGL(k_sel_sort_emit, dim3(n_real), dim3(256), SEL_SLOTS * sizeof(SelCand), s, G, n_real, top_n, st,
-                       cand, g->d_out_id.p + (size_t)first_seed_slot * top_n,
-                       g->d_out_score.p + (size_t)first_seed_slot * top_n, g->d_counts.p + first_seed_slot);
+    hipLaunchKernelGGL(k_sel_sort_emit, dim3(nseg), dim3(256), SEL_SLOTS * sizeof(SelCand), s, d_slot_k, top_n, st, cand,
+                       g->d_out_id.p, g->d_out_score.p, g->d_counts.p);
     RWR_HIP(hipGetLastError());
     return RWR_OK;
 }
