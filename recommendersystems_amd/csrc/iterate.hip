@@ -86,14 +86,20 @@ __global__ __launch_bounds__(256) void k_spmm(int32_t n, const int64_t *__restri
 // to the whole group through the LDS crossbar (ds_bpermute), instead of G lanes loading the
 // same address per edge.  All G row gathers of a chunk are issued before the first add, so
 // each lane keeps up to G 8-byte gathers in flight; the adds then run in list order.
-template <int G, int CH>
+//
+// Frontier awareness for the first iterations (x starts as a single non-zero row per seed and stays
+// sparse for two or three steps): CHECK consults a per-tile bitmap "row of X has a non-zero" before a
+// row gather and skips the gather of all-zero rows -- their addends are (1-d)*0*w = +0.0, which leave
+// the non-negative accumulator bitwise unchanged.  WRITE records the non-zero rows of Y for the next step.
+template <int G, int CH, bool CHECK, bool WRITE>
 __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *__restrict__ in_ptr,
                                                       const int32_t *__restrict__ in_src,
                                                       const double *__restrict__ in_w,
                                                       const int32_t *__restrict__ row_order,
                                                       const double *__restrict__ X, double *__restrict__ Y,
                                                       const int32_t *__restrict__ seeds, double c1,
-                                                      int skip_seed_row)
+                                                      int skip_seed_row, const uint32_t *__restrict__ nz_in,
+                                                      uint32_t *__restrict__ nz_out)
 {
     static_assert(G >= 8 && G <= 64, "chunked SpMM needs 8 <= G <= 64");
     constexpr int RPW = WAVE / G;
@@ -101,6 +107,9 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
     const size_t toff = (size_t)tile * (size_t)n * G;
     X += toff;
     Y += toff;
+    const size_t nzw = ((size_t)n + 31) / 32;
+    if (CHECK) nz_in += (size_t)tile * nzw;
+    if (WRITE) nz_out += (size_t)tile * nzw;
     const int lane = threadIdx.x & (WAVE - 1);
     const int sub = lane / G, k = lane % G;
     const int gbase = (lane - k) << 2;      // byte address of the group's lane 0 for ds_bpermute
@@ -126,6 +135,10 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
             if (k < cnt) {
                 my_idx = in_src[p + k];
                 my_w = in_w[p + k];
+                if (CHECK) {   // one bitmap probe per entry (by the lane that fetched it); dead rows get the sign bit
+                    const uint32_t wd = nz_in[(uint32_t)my_idx >> 5];
+                    if (!((wd >> (my_idx & 31)) & 1u)) my_idx |= (int32_t)0x80000000;
+                }
             }
             const int wlo = __double2loint(my_w), whi = __double2hiint(my_w);
             double xv[CH], wv[CH];
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
                 const int lo = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), wlo);
                 const int hi = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), whi);
                 wv[t] = __hiloint2double(hi, lo);
-                xv[t] = (t < cnt) ? X[(size_t)idx * G + k] : 0.0;
+                xv[t] = (t < cnt && idx >= 0) ? X[(size_t)idx * G + k] : 0.0;
             }
 #pragma unroll
             for (int t = 0; t < CH; ++t) {
@@ -147,6 +160,11 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
             p += cnt;
         }
         if (j >= 0 && j != my_seed) Y[(size_t)j * G + k] = acc;
+        if (WRITE) {
+            const unsigned long long nzb = __ballot(acc != 0.0);
+            const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << (sub * G));
+            if (k == 0 && j >= 0 && (nzb & gmask)) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
+        }
     }
 }
 
@@ -159,7 +177,8 @@ __global__ __launch_bounds__(64) void k_seed_chain(int32_t n, int ntiles, const 
                                                    const double *__restrict__ in_w,
                                                    const uint8_t *__restrict__ dangling,
                                                    const double *__restrict__ X, double *__restrict__ Y,
-                                                   const int32_t *__restrict__ seeds, double c1)
+                                                   const int32_t *__restrict__ seeds, double c1,
+                                                   uint32_t *__restrict__ nz_out)
 {
     constexpr int U = 8;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;   // (tile, k)
@@ -202,6 +221,8 @@ __global__ __launch_bounds__(64) void k_seed_chain(int32_t n, int ntiles, const 
         acc += dangling[i] ? xi : (xi - rw);
     }
     Y[(size_t)tile * (size_t)n * G + (size_t)s * G + k] = acc;
+    if (nz_out && acc != 0.0)
+        atomicOr(&nz_out[(size_t)tile * (((size_t)n + 31) / 32) + ((uint32_t)s >> 5)], 1u << (s & 31));
 }
 
 // EXACT mode helper: the addends of the links INTO each seed, ((1-d) x_src) * w in list order
@@ -226,48 +247,90 @@ __global__ __launch_bounds__(256) void k_seed_terms(int32_t n, const int64_t *__
     }
 }
 
-// EXACT mode, pipelined form of k_seed_chain: one 256-thread workgroup per tile.
-// All four waves stream the tile's rank matrix in 64 KiB chunks (coalesced, 32 loads in
-// flight per lane), turn each value into its restart addend
-//     rr_i = dangling_i ? x_i : x_i - (1-d)*x_i          (Model.cs:91,97)
-// and stage it in LDS (double-buffered); wave 0 then folds the staged addends into the
-// per-seed accumulators strictly in node order -- the n-term fp64 chain itself is
-// inherently sequential, so it runs at the dependent-add rate while the other waves hide
-// the memory latency.  Chunks that contain a source linking INTO a seed take the careful
-// path, which interleaves that link's addend before the node's restart addend exactly
-// as Model.cs:85-93 does.
-constexpr int CHAIN_CE = 8192;                 // doubles per chunk (64 KiB)
-template <int G, int NT, int NPF>
-__global__ __launch_bounds__(NT) void k_seed_chain_lds(int32_t n, const int64_t *__restrict__ in_ptr,
-                                                       const int32_t *__restrict__ in_src,
-                                                       const double *__restrict__ in_w,
-                                                       const uint8_t *__restrict__ dangling,
-                                                       const double *__restrict__ X, double *__restrict__ Y,
-                                                       const int32_t *__restrict__ seeds, double c1,
-                                                       const int64_t *__restrict__ evoff,
-                                                       const double *__restrict__ evterm, int dbg)
+// EXACT mode, role-specialised form (the default): wave 0 only FOLDS, waves 1-6 only STAGE.
+//   stagers: stream the tile's rank matrix in 48 KiB chunks, two chunks ahead of the fold (2 x 16 coalesced loads
+//            in flight per lane), turn each value into its restart addend
+//                rr_i = dangling_i ? x_i : x_i - (1-d)*x_i          (Model.cs:91,97)
+//            and write it to LDS (double-buffered);
+//   folder : adds the staged addends strictly in node order, 16 at a time from registers.  The addends of the
+//            links INTO a seed (computed by k_seed_terms) are prefetched per lane two links ahead into registers;
+//            a 32-row block that holds such a link is walked row by row so that the link's addend lands before
+//            the row's restart addend (Model.cs:85-93).  The folder issues no other global loads, so the n-term
+//            chain runs near the dependent v_add_f64 rate (~7.5 cycles per row).
+constexpr int CH3_NSW = 6;                      // stager waves
+constexpr int CH3_NST = CH3_NSW * WAVE;         // stager threads
+constexpr int CH3_LPT = 16;                     // loads per stager thread and chunk
+constexpr int CH3_CE = CH3_NST * CH3_LPT;       // 6144 doubles per chunk (48 KiB)
+template <int G>
+__global__ __launch_bounds__(WAVE + CH3_NST) void k_seed_chain_roles(
+    int32_t n, const int64_t *__restrict__ in_ptr, const int32_t *__restrict__ in_src,
+    const uint8_t *__restrict__ dangling, const double *__restrict__ X, double *__restrict__ Y,
+    const int32_t *__restrict__ seeds, double c1, const int64_t *__restrict__ evoff,
+    const double *__restrict__ evterm, uint32_t *__restrict__ nz_out, int dbg)
 {
-    // NT threads stage, NPF chunks are kept in flight in registers ahead of the one being folded
-    constexpr int CR = CHAIN_CE / G;           // rows per chunk
-    constexpr int LPT = CHAIN_CE / NT;         // loads per thread per chunk
-    extern __shared__ double chain_buf[];      // [2][CHAIN_CE]
+    constexpr int CR = CH3_CE / G;                         // rows per chunk (a multiple of 32)
+    static_assert(CR % 32 == 0, "chunk rows must be a multiple of 32");
+    extern __shared__ double rr[];                         // [2][CH3_CE]
     const int tile = blockIdx.x;
     const double *x = X + (size_t)tile * (size_t)n * G;
     const int tid = threadIdx.x;
-    const int64_t total = (int64_t)n * G;      // doubles in the tile
-    const int nchunks = (int)((total + CHAIN_CE - 1) / CHAIN_CE);
+    const int64_t total = (int64_t)n * G;
+    const int nchunks = (int)((total + CH3_CE - 1) / CH3_CE);
 
-    // consumer state (meaningful in wave 0, lanes < G)
+    if (tid >= WAVE) {
+        // ------------------------------------------------------------------ stagers
+        const int st = tid - WAVE;
+        double rega[CH3_LPT], regb[CH3_LPT];
+        uint8_t dga[CH3_LPT], dgb[CH3_LPT];
+#define CH3_LOAD(R, D, C)                                                       \
+    {                                                                           \
+        const int64_t base__ = (int64_t)(C) * CH3_CE;                           \
+        _Pragma("unroll") for (int u = 0; u < CH3_LPT; ++u) {                   \
+            int64_t el = base__ + (int64_t)u * CH3_NST + st;                    \
+            el = el < total ? el : total - 1;                                   \
+            if (dbg & 2) el = st;                                               \
+            R[u] = x[el];                                                       \
+            D[u] = dangling[el / G];                                            \
+        }                                                                       \
+    }
+#define CH3_STAGE(R, D, C)                                                                              \
+    {                                                                                                   \
+        const int64_t base__ = (int64_t)(C) * CH3_CE;                                                   \
+        double *buf__ = rr + (size_t)((C) & 1) * CH3_CE;                                                \
+        _Pragma("unroll") for (int u = 0; u < CH3_LPT; ++u) {                                           \
+            const int off = u * CH3_NST + st;                                                           \
+            const double xv = (base__ + off < total) ? R[u] : 0.0; /* past the end: +0.0, no effect */  \
+            const double rw = c1 * xv;                                                                  \
+            buf__[off] = D[u] ? xv : (xv - rw);                                                         \
+        }                                                                                               \
+    }
+        CH3_LOAD(rega, dga, 0)
+        if (nchunks > 1) CH3_LOAD(regb, dgb, 1)
+        for (int c = 0; c < nchunks; c += 2) {
+            CH3_STAGE(rega, dga, c)
+            if (c + 2 < nchunks) CH3_LOAD(rega, dga, c + 2)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            if (c + 1 < nchunks) {
+                CH3_STAGE(regb, dgb, c + 1)
+                if (c + 3 < nchunks) CH3_LOAD(regb, dgb, c + 3)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+#undef CH3_LOAD
+#undef CH3_STAGE
+        return;
+    }
+
+    // ---------------------------------------------------------------------- folder (wave 0)
     const bool consumer = tid < G;
     const int k = tid % G;
-    // Links INTO the seed: their addends ((1-d) x_src) * w were computed by k_seed_terms (list order).
-    // The lane keeps the current link (nxt, tcur) and the following one (nxt2, tcur2) in registers so
-    // that taking a link never waits on memory unless two links of one seed are a few rows apart.
     int32_t s = -1;
-    int64_t p = 0, e = 0;            // p = index of the link AFTER (nxt2, tcur2)
+    int64_t p = 0, e = 0;                                  // p = index of the link AFTER the pending one
     const int32_t *srcp = in_src;
     const double *termp = evterm;
-    int32_t nxt = INT_MAX, raw_s = INT_MAX;
+    int32_t nxt = INT_MAX, raw_s = INT_MAX;                // current link's source row; pending link's (raw load)
     double tcur = 0.0, raw_t = 0.0;
     bool has2 = false;
     if (consumer) {
@@ -275,106 +338,58 @@ __global__ __launch_bounds__(NT) void k_seed_chain_lds(int32_t n, const int64_t 
         if (s >= 0) {
             p = in_ptr[s];
             e = in_ptr[s + 1];
-            termp = evterm + evoff[tile * G + k] - p;      // termp[link index] = term of that link
+            termp = evterm + evoff[tile * G + k] - p;      // termp[link index] = addend of that link
             if (p < e) { nxt = srcp[p]; tcur = termp[p]; ++p; }
             if (p < e) { raw_s = srcp[p]; raw_t = termp[p]; has2 = true; ++p; }
         }
     }
     double acc = 0.0;
-
-    // branch-free, clamped loads so that all loads of a chunk are in flight together
-    double reg[NPF][LPT];
-    uint8_t dreg[NPF][LPT];
-#define CHAIN_LOAD(SLOT, C)                                                \
-    {                                                                      \
-        const int64_t base__ = (int64_t)(C) * CHAIN_CE;                    \
-        _Pragma("unroll") for (int q = 0; q < LPT; ++q) {                  \
-            int64_t el = base__ + (int64_t)q * NT + tid;                   \
-            el = el < total ? el : total - 1;                              \
-            reg[SLOT][q] = x[el];                                          \
-            dreg[SLOT][q] = dangling[el / G];                              \
-        }                                                                  \
-    }
-#define CHAIN_STAGE(SLOT, C)                                                                          \
-    {                                                                                                 \
-        const int64_t base__ = (int64_t)(C) * CHAIN_CE;                                               \
-        double *buf__ = chain_buf + (size_t)((C) & 1) * CHAIN_CE;                                     \
-        _Pragma("unroll") for (int q = 0; q < LPT; ++q) {                                             \
-            const int off = q * NT + tid;                                                             \
-            const double xv = (base__ + off < total) ? reg[SLOT][q] : 0.0; /* past the end: +0.0 */   \
-            const double rw = c1 * xv;                                                                \
-            buf__[off] = dreg[SLOT][q] ? xv : (xv - rw);                                              \
-        }                                                                                             \
-    }
-
+    __builtin_amdgcn_s_setprio(3);
+    for (int c = 0; c < nchunks; ++c) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        const double *buf = rr + (size_t)(c & 1) * CH3_CE;
+        const int64_t row0 = (int64_t)c * CR;
+        // 32-row blocks: all 32 LDS reads are issued up front, the adds consume them in order (each waits only
+        // for its own operand), so one LDS latency is exposed per 32 rows.  A block that holds a link into one of
+        // the tile's seeds is walked row by row instead (re-reading LDS; deliberately not unrolled).
+        for (int r0 = 0; r0 < ((dbg & 1) ? 32 : CR); r0 += 32) {
+            double v[32];
 #pragma unroll
-    for (int ph = 0; ph < NPF; ++ph)
-        if (ph < nchunks) CHAIN_LOAD(ph, ph);
-    for (int c0 = 0; c0 < nchunks; c0 += NPF) {
+            for (int u = 0; u < 32; ++u) v[u] = buf[(r0 + u) * G + k];
+            const bool evt = __any(consumer && nxt < row0 + r0 + 32) && !(dbg & 4);
+            if (!evt) {
 #pragma unroll
-        for (int ph = 0; ph < NPF; ++ph) {
-            const int c = c0 + ph;
-            if (c >= nchunks) break;                       // block-uniform
-            if (!(dbg & 2)) {
-                CHAIN_STAGE(ph, c);
-                if (c + NPF < nchunks) CHAIN_LOAD(ph, c + NPF);
-            }
-            // LDS-only barrier: __syncthreads() would also drain vmcnt and expose the latency of the
-            // prefetch loads just issued; only the staged LDS writes have to be complete here
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            if (tid < WAVE && !(dbg & 1)) {   // wave 0 folds chunk c
-                const double *buf = chain_buf + (size_t)(c & 1) * CHAIN_CE;
-                const int64_t row0 = (int64_t)c * CR;
-                // 16-row sub-blocks, software-pipelined: the LDS reads of the next sub-block are issued
-                // before the dependent adds of the current one.  The common sub-block has no link into any
-                // seed of the tile and is a pure add chain; the rare one checks every row (per lane).
-                __builtin_amdgcn_s_setprio(3);
-                double va[16], vb[16];
-#define CHAIN_READ(V, R0) _Pragma("unroll") for (int u = 0; u < 16; ++u) V[u] = buf[((R0) + u) * G + k];
-#define CHAIN_FOLD(V, R0)                                                                              \
-    {                                                                                                  \
-        const bool evt = __any(consumer && nxt < row0 + (R0) + 16);                                    \
-        if (!evt) {                                                                                    \
-            _Pragma("unroll") for (int u = 0; u < 16; ++u) acc += V[u];                                \
-        } else {                                                                                       \
-            _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                           \
-                const int64_t i = row0 + (R0) + u;                                                     \
-                while (consumer && nxt == i) { /* links i -> seed come first (Model.cs:85-88) */       \
-                    acc += tcur;                                                                       \
-                    /* promote the pending link (its loads were issued at the previous take) ... */    \
-                    nxt = has2 ? raw_s : INT_MAX;                                                      \
-                    tcur = raw_t;                                                                      \
-                    /* ... and issue the loads of the one after it; they are not touched until then */ \
-                    has2 = p < e;                                                                      \
-                    const int64_t pc = has2 ? p : e - 1;                                               \
-                    raw_s = srcp[pc];                                                                  \
-                    raw_t = termp[pc];                                                                 \
-                    p += has2 ? 1 : 0;                                                                 \
-                }                                                                                      \
-                acc += V[u]; /* then the restart addend (Model.cs:91-93,96-97) */                      \
-            }                                                                                          \
-        }                                                                                              \
-    }
-                CHAIN_READ(va, 0)
-                for (int r0 = 0; r0 < CR; r0 += 32) {
-                    CHAIN_READ(vb, r0 + 16)
-                    CHAIN_FOLD(va, r0)
-                    if (r0 + 32 < CR) CHAIN_READ(va, r0 + 32)
-                    CHAIN_FOLD(vb, r0 + 16)
+                for (int u = 0; u < 32; ++u) acc += v[u];
+            } else {
+                // rare block: same adds from the same registers, but before row u every lane whose pending link
+                // comes from that row takes it first (Model.cs:85-88); the branch is wave-uniformly skipped otherwise
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const int32_t i = (int32_t)(row0 + r0) + u;
+                    if (__any(consumer && nxt == i)) {
+                        while (consumer && nxt == i) {
+                            acc += tcur;
+                            nxt = has2 ? raw_s : INT_MAX;  // promote the pending link (loaded at the previous take)
+                            tcur = raw_t;
+                            has2 = p < e;                  // and fetch the one after it; untouched until then
+                            const int64_t pc = has2 ? p : e - 1;
+                            raw_s = srcp[pc];
+                            raw_t = termp[pc];
+                            p += has2 ? 1 : 0;
+                        }
+                    }
+                    acc += v[u];                           // then the restart addend (Model.cs:91-93,96-97)
                 }
-#undef CHAIN_READ
-#undef CHAIN_FOLD
-                __builtin_amdgcn_s_setprio(0);
             }
-            // no second barrier: chunk c+2 is staged into this buffer only after every wave has passed
-            // the barrier of phase c+1, which wave 0 reaches after finishing this fold
         }
     }
-#undef CHAIN_LOAD
-#undef CHAIN_STAGE
-    if (consumer && s >= 0) Y[(size_t)tile * (size_t)n * G + (size_t)s * G + k] = acc;
+    __builtin_amdgcn_s_setprio(0);
+    if (consumer && s >= 0) {
+        Y[(size_t)tile * (size_t)n * G + (size_t)s * G + k] = acc;
+        if (nz_out && acc != 0.0)
+            atomicOr(&nz_out[(size_t)tile * (((size_t)n + 31) / 32) + ((uint32_t)s >> 5)], 1u << (s & 31));
+    }
 }
 
 // FAST mode: restart mass R_k = sum_i (dangling_i ? x_i : x_i - (1-d) x_i), deterministic tree.
@@ -406,7 +421,8 @@ __global__ __launch_bounds__(RP_BLOCK) void k_restart_partial(int32_t n, const u
 
 template <int G>
 __global__ void k_restart_final(int32_t n, int ntiles, int nblk, const double *__restrict__ part,
-                                double *__restrict__ Y, const int32_t *__restrict__ seeds)
+                                double *__restrict__ Y, const int32_t *__restrict__ seeds,
+                                uint32_t *__restrict__ nz_out)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= ntiles * G) return;
@@ -416,18 +432,22 @@ __global__ void k_restart_final(int32_t n, int ntiles, int nblk, const double *_
     double R = 0.0;
     for (int b = 0; b < nblk; ++b) R += part[((size_t)tile * nblk + b) * G + k];
     double *y = Y + (size_t)tile * (size_t)n * G + (size_t)s * G + k;
-    *y = *y + R;
+    const double v = *y + R;
+    *y = v;
+    if (nz_out && v != 0.0)
+        atomicOr(&nz_out[(size_t)tile * (((size_t)n + 31) / 32) + ((uint32_t)s >> 5)], 1u << (s & 31));
 }
 
 // Model ctor, Model.cs:42-49: rank[seed] = nNodes, everything else 0
 __global__ void k_init_seeds(int32_t n, int ntiles, int G, double *__restrict__ X,
-                             const int32_t *__restrict__ seeds)
+                             const int32_t *__restrict__ seeds, uint32_t *__restrict__ nz)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= ntiles * G) return;
     const int32_t s = seeds[q];
     if (s < 0) return;
     X[(size_t)(q / G) * (size_t)n * G + (size_t)s * G + (q % G)] = (double)n;
+    if (nz) atomicOr(&nz[(size_t)(q / G) * (((size_t)n + 31) / 32) + ((uint32_t)s >> 5)], 1u << (s & 31));
 }
 
 // Recommender.cs:20-24,29: the seed's RAW out-links of type LIKE are not candidates.
@@ -449,21 +469,22 @@ __global__ void k_exclude(int32_t n, int ntiles, int G, const int64_t *__restric
 
 template <int G>
 static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
-                        int skip, hipStream_t s)
+                        int skip, const uint32_t *nz_in, uint32_t *nz_out, hipStream_t s)
 {
     constexpr int RPW = WAVE / G;
     unsigned want = cdiv((size_t)g->n, (size_t)RPW * 4);
     unsigned gx = want < 8192u ? want : 8192u;
     static const int variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
     if constexpr (G >= 8) {
-        if (variant == 1) {
-            hipLaunchKernelGGL((k_spmm_chunked<G, (G > 16 ? 16 : G)>), dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p,
-                               g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip);
-            return;
-        }
-        if (variant == 2) {
-            hipLaunchKernelGGL((k_spmm_chunked<G, 8>), dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p,
-                               g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip);
+        if (variant != 0) {
+            constexpr int CH = (G > 16 ? 16 : G);
+#define RWR_SPMM_LAUNCH(CHK, WR)                                                                                   \
+    hipLaunchKernelGGL((k_spmm_chunked<G, CH, CHK, WR>), dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p,         \
+                       g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, nz_in, nz_out)
+            if (nz_in && nz_out) RWR_SPMM_LAUNCH(true, true);
+            else if (nz_in) RWR_SPMM_LAUNCH(true, false);
+            else RWR_SPMM_LAUNCH(false, false);
+#undef RWR_SPMM_LAUNCH
             return;
         }
     }
@@ -472,33 +493,26 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
 }
 template <int G>
 static void launch_chain(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
-                         const int64_t *evoff, hipStream_t s)
+                         const int64_t *evoff, uint32_t *nz_out, hipStream_t s)
 {
     const unsigned term_blocks = g->max_in_deg > 256 * 8 ? 8u : cdiv((size_t)(g->max_in_deg > 0 ? g->max_in_deg : 1), 256);
-    static const int variant = [] { const char *e = getenv("RWR_CHAIN"); return e ? atoi(e) : 1; }();
+    static const int variant = [] { const char *e = getenv("RWR_CHAIN"); return e ? atoi(e) : 1; }();   // 0 = simple reference kernel
     static const int dbg = [] { const char *e = getenv("RWR_CHAIN_DBG"); return e ? atoi(e) : 0; }();
-#define RWR_CHAIN_LAUNCH(NT, NPF)                                                                                  \
-    {                                                                                                              \
-        static const bool attr_ok = [] {                                                                           \
-            return hipFuncSetAttribute((const void *)k_seed_chain_lds<G, NT, NPF>,                                 \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,                                 \
-                                       2 * CHAIN_CE * (int)sizeof(double)) == hipSuccess;                          \
-        }();                                                                                                       \
-        (void)attr_ok;                                                                                             \
-        hipLaunchKernelGGL(k_seed_terms<G>, dim3(term_blocks, tg * G), dim3(256), 0, s, g->n, g->in_ptr.p,          \
-                           g->in_src.p, g->in_w.p, X, seeds, c1, evoff, g->d_evterm.p);                            \
-        hipLaunchKernelGGL((k_seed_chain_lds<G, NT, NPF>), dim3(tg), dim3(NT), 2 * CHAIN_CE * sizeof(double), s,   \
-                           g->n, g->in_ptr.p, g->in_src.p, g->in_w.p, g->dangling.p, X, Y, seeds, c1, evoff,       \
-                           g->d_evterm.p, dbg);                                                                    \
-        return;                                                                                                    \
+    if (variant != 0) {
+        constexpr size_t smem = 2 * CH3_CE * sizeof(double);
+        static const bool attr_ok5 = [] {
+            return hipFuncSetAttribute((const void *)k_seed_chain_roles<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)smem) == hipSuccess;
+        }();
+        (void)attr_ok5;
+        hipLaunchKernelGGL(k_seed_terms<G>, dim3(term_blocks, tg * G), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p,
+                           g->in_w.p, X, seeds, c1, evoff, g->d_evterm.p);
+        hipLaunchKernelGGL(k_seed_chain_roles<G>, dim3(tg), dim3(WAVE + CH3_NST), smem, s, g->n, g->in_ptr.p,
+                           g->in_src.p, g->dangling.p, X, Y, seeds, c1, evoff, g->d_evterm.p, nz_out, dbg);
+        return;
     }
-    if (variant == 1) RWR_CHAIN_LAUNCH(256, 1)
-    if (variant == 2) RWR_CHAIN_LAUNCH(512, 2)
-    if (variant == 3) RWR_CHAIN_LAUNCH(1024, 4)
-    if (variant == 4) RWR_CHAIN_LAUNCH(256, 2)
-#undef RWR_CHAIN_LAUNCH
     hipLaunchKernelGGL(k_seed_chain<G>, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, g->n, tg, g->in_ptr.p,
-                       g->in_src.p, g->in_w.p, g->dangling.p, X, Y, seeds, c1);
+                       g->in_src.p, g->in_w.p, g->dangling.p, X, Y, seeds, c1, nz_out);
 }
 constexpr int RP_GRID = 512;
 template <int G>
@@ -508,10 +522,11 @@ static void launch_restart_partial(rwr_graph *g, int tg, const double *X, double
                        g->d_part.p, c1);
 }
 template <int G>
-static void launch_restart_final(rwr_graph *g, int tg, double *Y, const int32_t *seeds, hipStream_t s)
+static void launch_restart_final(rwr_graph *g, int tg, double *Y, const int32_t *seeds, uint32_t *nz_out,
+                                 hipStream_t s)
 {
     hipLaunchKernelGGL(k_restart_final<G>, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, g->n, tg, RP_GRID,
-                       g->d_part.p, Y, seeds);
+                       g->d_part.p, Y, seeds, nz_out);
 }
 
 #define RWR_DISPATCH_G(G, CALL)                 \
@@ -571,8 +586,19 @@ int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, const
     double *X = g->X.p, *Y = g->Y.p;
     const size_t elems = (size_t)tg * (size_t)n * G;
     RWR_HIP(hipMemsetAsync(X, 0, elems * sizeof(double), s));
-    hipLaunchKernelGGL(k_init_seeds, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, X, d_seeds);
+    // frontier bitmaps for the first iterations (chunked SpMM only)
+    static const int nz_iters_env = [] { const char *e = getenv("RWR_NZ_ITERS"); return e ? atoi(e) : 3; }();
+    static const int spmm_variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
+    const int nz_iters = (G >= 8 && spmm_variant != 0) ? nz_iters_env : 0;
+    const size_t nzw = ((size_t)n + 31) / 32;
+    uint32_t *nz_cur = nz_iters > 0 ? g->d_nz.p : nullptr;
+    uint32_t *nz_oth = nz_iters > 0 ? g->d_nz.p + (size_t)tg * nzw : nullptr;
+    if (nz_cur) RWR_HIP(hipMemsetAsync(nz_cur, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_init_seeds, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, X, d_seeds, nz_cur);
     for (int64_t it = 0; it < n_iter; ++it) {
+        const uint32_t *nz_in = (it < nz_iters) ? nz_cur : nullptr;
+        uint32_t *nz_out = (it + 1 < nz_iters) ? nz_oth : nullptr;
+        if (nz_out) RWR_HIP(hipMemsetAsync(nz_out, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
         static const int serial = [] { const char *e = getenv("RWR_CHAIN_SERIAL"); return e ? atoi(e) : 0; }();
         if (exact && serial) s2 = s;
         if (exact) {
@@ -581,7 +607,7 @@ int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, const
             if (s2 != s) RWR_HIP(hipStreamWaitEvent(s2, g->ev_fork, 0));
             hipEvent_t c0 = nullptr, c1e = nullptr;
             if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, s2)); }
-            RWR_DISPATCH_G(G, launch_chain<GG>(g, tg, X, Y, d_seeds, c1, d_evoff, s2));
+            RWR_DISPATCH_G(G, launch_chain<GG>(g, tg, X, Y, d_seeds, c1, d_evoff, nz_out, s2));
             if (prof) { RWR_HIP(hipEventRecord(c1e, s2)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
             RWR_HIP(hipEventRecord(g->ev_join, s2));
         } else {
@@ -592,15 +618,16 @@ int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, const
         }
         hipEvent_t a = nullptr, b = nullptr;
         if (prof) { a = pool.get(); b = pool.get(); RWR_HIP(hipEventRecord(a, s)); }
-        RWR_DISPATCH_G(G, launch_spmm<GG>(g, tg, X, Y, d_seeds, c1, exact ? 1 : 0, s));
+        RWR_DISPATCH_G(G, launch_spmm<GG>(g, tg, X, Y, d_seeds, c1, exact ? 1 : 0, nz_in, nz_out, s));
         if (prof) { RWR_HIP(hipEventRecord(b, s)); spmm_ev.push_back(a); spmm_ev.push_back(b); }
         if (exact) {
             if (s2 != s) RWR_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
         } else {
-            RWR_DISPATCH_G(G, launch_restart_final<GG>(g, tg, Y, d_seeds, s));
+            RWR_DISPATCH_G(G, launch_restart_final<GG>(g, tg, Y, d_seeds, nz_out, s));
         }
         RWR_HIP(hipGetLastError());
         double *t = X; X = Y; Y = t;   // Model.updateRanks (Model.cs:103-108)
+        { uint32_t *tz = nz_cur; nz_cur = nz_oth; nz_oth = tz; }
         g->stats.spmm_launches += 1;
         g->stats.chain_launches += 1;
     }
@@ -629,6 +656,7 @@ static int32_t ensure_workspace(rwr_graph *g, int G, int32_t K, int *TG_out)
     RWR_TRY(g->Y.ensure((size_t)TG * n * G));
     RWR_TRY(g->d_seeds.ensure((size_t)ntiles * G));
     RWR_TRY(g->d_part.ensure((size_t)TG * RP_GRID * G));
+    RWR_TRY(g->d_nz.ensure(2 * (size_t)TG * ((n + 31) / 32)));
     *TG_out = TG;
     return RWR_OK;
 }
