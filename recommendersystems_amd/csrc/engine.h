@@ -39,6 +39,7 @@ struct rwr_graph {
     rwr::DevBuf<int32_t> d_seeds;     // [tile][G], -1 = padding lane
     rwr::DevBuf<int32_t> d_slot_k;    // [tile][G]: batch position of the seed in this slot (-1 = padding)
     rwr::DevBuf<double> d_part;       // fast mode: restart partial sums
+    rwr::DevBuf<unsigned int> d_gate;   // exact mode: check-in counter of the resident chain workgroups
     rwr::DevBuf<uint32_t> d_nz;       // [2][tile][ceil(n/32)] bitmaps: row of X / Y has a non-zero (first iterations)
     rwr::DevBuf<int64_t> d_evoff;     // exact mode: per seed slot, offset of its in-link terms in d_evterm
     rwr::DevBuf<double> d_evterm;     // exact mode: ((1-d) x_src) * w of every link INTO a seed, list order

@@ -103,6 +103,11 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
 {
     static_assert(G >= 8 && G <= 64, "chunked SpMM needs 8 <= G <= 64");
     constexpr int RPW = WAVE / G;
+    // 512 B of LDS per block that the kernel never needs: it only makes the block non-placeable on a CU whose
+    // whole LDS was claimed by an exact-mode chain workgroup, so that the latency-critical chain keeps its CU's
+    // memory pipeline to itself instead of queueing behind this kernel's gathers
+    __shared__ int lds_token[128];
+    if (n < 0) lds_token[threadIdx.x & 127] = 1;   // never true; keeps the allocation
     const int tile = blockIdx.y;
     const size_t toff = (size_t)tile * (size_t)n * G;
     X += toff;
@@ -225,6 +230,19 @@ __global__ __launch_bounds__(64) void k_seed_chain(int32_t n, int ntiles, const 
         atomicOr(&nz_out[(size_t)tile * (((size_t)n + 31) / 32) + ((uint32_t)s >> 5)], 1u << (s & 31));
 }
 
+// Holds the main stream until `expected` chain workgroups have checked in (or ~1 ms has passed: the spin is
+// bounded, so a chain kernel that cannot become fully resident only costs the overlap, never a hang).
+// Without it the chain kernel, although launched first on a high-priority stream, is dispatched only after the
+// SpMM's ~half-million workgroups have all been issued, i.e. it runs after the SpMM instead of beside it.
+__global__ void k_gate(const unsigned int *__restrict__ gate, unsigned int expected)
+{
+    const long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+    while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000) break;  // 1 ms
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
 // EXACT mode helper: the addends of the links INTO each seed, ((1-d) x_src) * w in list order
 // (Model.cs:84,87 for target == seed), computed in parallel ahead of the sequential fold.
 template <int G>
@@ -266,8 +284,10 @@ __global__ __launch_bounds__(WAVE + CH3_NST) void k_seed_chain_roles(
     int32_t n, const int64_t *__restrict__ in_ptr, const int32_t *__restrict__ in_src,
     const uint8_t *__restrict__ dangling, const double *__restrict__ X, double *__restrict__ Y,
     const int32_t *__restrict__ seeds, double c1, const int64_t *__restrict__ evoff,
-    const double *__restrict__ evterm, uint32_t *__restrict__ nz_out, int dbg)
+    const double *__restrict__ evterm, uint32_t *__restrict__ nz_out, int dbg, unsigned int *__restrict__ gate)
 {
+    // check in: the main stream holds the SpMM back (k_gate) until the chain workgroups own their CUs
+    if (threadIdx.x == 0 && gate) __hip_atomic_fetch_add(gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr int CR = CH3_CE / G;                         // rows per chunk (a multiple of 32)
     static_assert(CR % 32 == 0, "chunk rows must be a multiple of 32");
     extern __shared__ double rr[];                         // [2][CH3_CE]
@@ -477,13 +497,22 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
     static const int variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
     if constexpr (G >= 8) {
         if (variant != 0) {
-            constexpr int CH = (G > 16 ? 16 : G);
-#define RWR_SPMM_LAUNCH(CHK, WR)                                                                                   \
-    hipLaunchKernelGGL((k_spmm_chunked<G, CH, CHK, WR>), dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p,         \
+            // experiment knob: dynamic LDS per block that caps the blocks per CU (0 = no cap)
+            static const size_t occ_lds = [] { const char *e = getenv("RWR_SPMM_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
+#define RWR_SPMM_LAUNCH2(CH, CHK, WR)                                                                              \
+    hipLaunchKernelGGL((k_spmm_chunked<G, CH, CHK, WR>), dim3(gx, tg), dim3(256), occ_lds, s, g->n, g->in_ptr.p,   \
                        g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, nz_in, nz_out)
-            if (nz_in && nz_out) RWR_SPMM_LAUNCH(true, true);
-            else if (nz_in) RWR_SPMM_LAUNCH(true, false);
-            else RWR_SPMM_LAUNCH(false, false);
+#define RWR_SPMM_LAUNCH(CH)                                  \
+    {                                                        \
+        if (nz_in && nz_out) RWR_SPMM_LAUNCH2(CH, true, true);   \
+        else if (nz_in) RWR_SPMM_LAUNCH2(CH, true, false);       \
+        else RWR_SPMM_LAUNCH2(CH, false, false);                 \
+    }
+            // entries per chunk = row gathers in flight per lane (variant 2: 8, variant 3: 4)
+            if (variant == 2) RWR_SPMM_LAUNCH(8)
+            else if (variant == 3) RWR_SPMM_LAUNCH(4)
+            else RWR_SPMM_LAUNCH((G > 16 ? 16 : G))
+#undef RWR_SPMM_LAUNCH2
 #undef RWR_SPMM_LAUNCH
             return;
         }
@@ -492,23 +521,33 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
                        g->row_order.p, X, Y, seeds, c1, skip);
 }
 template <int G>
-static void launch_chain(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
-                         const int64_t *evoff, uint32_t *nz_out, hipStream_t s)
+// the addends of the links into the seeds; tiny, runs on the MAIN stream ahead of the fork so that the chain kernel is
+// the first thing its stream has to dispatch once the fork event fires (it must get its CUs before the SpMM's
+// half-million workgroups flood the dispatcher, or it only starts when the SpMM drains)
+static void launch_seed_terms(rwr_graph *g, int tg, const double *X, const int32_t *seeds, double c1,
+                              const int64_t *evoff, hipStream_t s)
 {
     const unsigned term_blocks = g->max_in_deg > 256 * 8 ? 8u : cdiv((size_t)(g->max_in_deg > 0 ? g->max_in_deg : 1), 256);
+    hipLaunchKernelGGL(k_seed_terms<G>, dim3(term_blocks, tg * G), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p,
+                       g->in_w.p, X, seeds, c1, evoff, g->d_evterm.p);
+}
+template <int G>
+static void launch_chain(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
+                         const int64_t *evoff, uint32_t *nz_out, unsigned int *gate, hipStream_t s)
+{
     static const int variant = [] { const char *e = getenv("RWR_CHAIN"); return e ? atoi(e) : 1; }();   // 0 = simple reference kernel
     static const int dbg = [] { const char *e = getenv("RWR_CHAIN_DBG"); return e ? atoi(e) : 0; }();
     if (variant != 0) {
-        constexpr size_t smem = 2 * CH3_CE * sizeof(double);
+        // with few tiles in flight each chain workgroup claims a whole CU (all 160 KiB of LDS): see k_spmm_chunked
+        static const int excl = [] { const char *e = getenv("RWR_CHAIN_EXCL"); return e ? atoi(e) : 1; }();
+        const size_t smem = (excl && tg <= 64) ? (size_t)160 * 1024 : 2 * CH3_CE * sizeof(double);
         static const bool attr_ok5 = [] {
             return hipFuncSetAttribute((const void *)k_seed_chain_roles<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)smem) == hipSuccess;
+                                       160 * 1024) == hipSuccess;
         }();
         (void)attr_ok5;
-        hipLaunchKernelGGL(k_seed_terms<G>, dim3(term_blocks, tg * G), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p,
-                           g->in_w.p, X, seeds, c1, evoff, g->d_evterm.p);
         hipLaunchKernelGGL(k_seed_chain_roles<G>, dim3(tg), dim3(WAVE + CH3_NST), smem, s, g->n, g->in_ptr.p,
-                           g->in_src.p, g->dangling.p, X, Y, seeds, c1, evoff, g->d_evterm.p, nz_out, dbg);
+                           g->in_src.p, g->dangling.p, X, Y, seeds, c1, evoff, g->d_evterm.p, nz_out, dbg, gate);
         return;
     }
     hipLaunchKernelGGL(k_seed_chain<G>, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, g->n, tg, g->in_ptr.p,
@@ -595,6 +634,9 @@ int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, const
     uint32_t *nz_oth = nz_iters > 0 ? g->d_nz.p + (size_t)tg * nzw : nullptr;
     if (nz_cur) RWR_HIP(hipMemsetAsync(nz_cur, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
     hipLaunchKernelGGL(k_init_seeds, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, X, d_seeds, nz_cur);
+    constexpr int GATE_SLOTS = 64;
+    static const int use_gate = [] { const char *e = getenv("RWR_GATE"); return e ? atoi(e) : 1; }();
+    unsigned int *gate_it = nullptr;
     for (int64_t it = 0; it < n_iter; ++it) {
         const uint32_t *nz_in = (it < nz_iters) ? nz_cur : nullptr;
         uint32_t *nz_out = (it + 1 < nz_iters) ? nz_oth : nullptr;
@@ -603,11 +645,14 @@ int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, const
         if (exact && serial) s2 = s;
         if (exact) {
             // fork: the seed-row chain runs beside the SpMM on the second stream
+            RWR_DISPATCH_G(G, launch_seed_terms<GG>(g, tg, X, d_seeds, c1, d_evoff, s));
+            gate_it = (use_gate && s2 != s) ? g->d_gate.p + (it % GATE_SLOTS) : nullptr;
+            if (gate_it) RWR_HIP(hipMemsetAsync(gate_it, 0, sizeof(unsigned int), s));
             RWR_HIP(hipEventRecord(g->ev_fork, s));
             if (s2 != s) RWR_HIP(hipStreamWaitEvent(s2, g->ev_fork, 0));
             hipEvent_t c0 = nullptr, c1e = nullptr;
             if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, s2)); }
-            RWR_DISPATCH_G(G, launch_chain<GG>(g, tg, X, Y, d_seeds, c1, d_evoff, nz_out, s2));
+            RWR_DISPATCH_G(G, launch_chain<GG>(g, tg, X, Y, d_seeds, c1, d_evoff, nz_out, gate_it, s2));
             if (prof) { RWR_HIP(hipEventRecord(c1e, s2)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
             RWR_HIP(hipEventRecord(g->ev_join, s2));
         } else {
@@ -615,6 +660,10 @@ int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, const
             if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, s)); }
             RWR_DISPATCH_G(G, launch_restart_partial<GG>(g, tg, X, c1, s));
             if (prof) { RWR_HIP(hipEventRecord(c1e, s)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
+        }
+        if (exact && gate_it) {
+            const unsigned expected = (unsigned)(tg < 192 ? tg : 192);
+            hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, gate_it, expected);
         }
         hipEvent_t a = nullptr, b = nullptr;
         if (prof) { a = pool.get(); b = pool.get(); RWR_HIP(hipEventRecord(a, s)); }
@@ -657,6 +706,7 @@ static int32_t ensure_workspace(rwr_graph *g, int G, int32_t K, int *TG_out)
     RWR_TRY(g->d_seeds.ensure((size_t)ntiles * G));
     RWR_TRY(g->d_part.ensure((size_t)TG * RP_GRID * G));
     RWR_TRY(g->d_nz.ensure(2 * (size_t)TG * ((n + 31) / 32)));
+    RWR_TRY(g->d_gate.ensure(64));
     *TG_out = TG;
     return RWR_OK;
 }
