@@ -127,6 +127,14 @@ def main():
         bytes_total = launches * (nnz * 12 + (n + 1) * 8 + n) + st["spmm_seed_steps"] * (16 * n + 12)
         spmm_s = st["spmm_ms"] / 1e3
         achieved = bytes_total / spmm_s / 1e9 if spmm_s > 0 else 0.0
+        # HBM-side bytes per SpMM launch from the committed rocprofv3 PMC passes of this same command (the PMC passes
+        # cannot run inside the timed run); null when no measurement exists for this configuration
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("mode") == args.mode and tj.get("tile_seeds") == st["tile_seeds"] and K == K_cfg:
+                traffic = tj["bytes_per_launch"]
         out = {
             "metric": "RWR seeds/sec + achieved HBM GB/s on 100M-edge bipartite graph, 1/2/4/8 GPUs",
             "value": value, "unit": "seeds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -140,7 +148,7 @@ def main():
                        "tile_seeds": st["tile_seeds"], "tile_group": st["tile_group"],
                        "parallelism": f"seed-sharded x{world} (graph replicated, no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "k_spmm", "launches": launches,
                          "avg_launch_ms": st["spmm_ms"] / max(launches, 1),
                          "algorithmic_bytes_per_launch": bytes_total / max(launches, 1)},
