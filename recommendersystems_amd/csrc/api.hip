@@ -229,14 +229,11 @@ int32_t rwr_model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, do
     g_err[0] = 0;
     if (!g || !rank_out) { set_error("rwr_model_run: NULL argument"); return RWR_E_INVALID; }
     RWR_TRY(bind_device(g));
-    if (seed == -1 || run_mode != RWR_RUN_ITERATIONS) {
-        set_error("rwr_model_run: the global model (seed -1) and threshold runs are not implemented yet");
-        return RWR_E_UNSUPPORTED;
+    if (run_mode != RWR_RUN_ITERATIONS && run_mode != RWR_RUN_THRESHOLD && run_mode != RWR_RUN_DEFAULT_THRESHOLD) {
+        set_error("rwr_model_run: unknown run_mode %d", run_mode);
+        return RWR_E_INVALID;
     }
-    int64_t T = (int64_t)value;
-    if (T < 0) T = 0;
-    RWR_TRY(model_run_iters(g, seed, d, T, rank_out));
-    if (iters_out) *iters_out = T;
+    RWR_TRY(model_run(g, seed, d, run_mode, value, rank_out, iters_out));
     return RWR_OK;
 }
 

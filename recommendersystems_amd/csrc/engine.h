@@ -66,6 +66,7 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
 // (mode 0: top-k into host arrays; mode 1: full rank vector of one seed)
 int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d, int32_t n_iter, int32_t top_n,
                         int64_t *ids, double *scores, int32_t *counts, int64_t row_stride);
-int32_t model_run_iters(rwr_graph *g, int32_t seed, double d, int64_t n_iter, double *rank_out);
+int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double value, double *rank_out,
+                  int64_t *iters_out);
 
 }  // namespace rwr

@@ -613,35 +613,57 @@ static int resolve_G(const rwr_graph *g, int32_t K)
     return want;
 }
 
-int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, const int64_t *d_evoff, double d,
-                      int64_t n_iter, double **final_X, EvPool &pool, std::vector<hipEvent_t> &spmm_ev,
-                      std::vector<hipEvent_t> &chain_ev)
-{
-    const int32_t n = g->n;
-    const double c1 = 1 - d;   // Model.cs:84: (1 - dampingFactor)
-    hipStream_t s = g->stream, s2 = g->stream2;
-    const bool exact = g->opts.mode != RWR_MODE_FAST;
-    const bool prof = g->opts.profile != 0;
-    double *X = g->X.p, *Y = g->Y.p;
-    const size_t elems = (size_t)tg * (size_t)n * G;
-    RWR_HIP(hipMemsetAsync(X, 0, elems * sizeof(double), s));
-    // frontier bitmaps for the first iterations (chunked SpMM only)
-    static const int nz_iters_env = [] { const char *e = getenv("RWR_NZ_ITERS"); return e ? atoi(e) : 3; }();
-    static const int spmm_variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
-    const int nz_iters = (G >= 8 && spmm_variant != 0) ? nz_iters_env : 0;
-    const size_t nzw = ((size_t)n + 31) / 32;
-    uint32_t *nz_cur = nz_iters > 0 ? g->d_nz.p : nullptr;
-    uint32_t *nz_oth = nz_iters > 0 ? g->d_nz.p + (size_t)tg * nzw : nullptr;
-    if (nz_cur) RWR_HIP(hipMemsetAsync(nz_cur, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_init_seeds, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, X, d_seeds, nz_cur);
-    constexpr int GATE_SLOTS = 64;
-    static const int use_gate = [] { const char *e = getenv("RWR_GATE"); return e ? atoi(e) : 1; }();
-    unsigned int *gate_it = nullptr;
-    for (int64_t it = 0; it < n_iter; ++it) {
+// One tile group's power iteration: init() = Model ctor (Model.cs:33-50), step() = deliverRanks + updateRanks
+// (Model.cs:76-108).  After step() `X` holds the new ranks and `Y` still holds the previous ones.
+struct GroupIter {
+    rwr_graph *g;
+    int G, tg;
+    const int32_t *d_seeds;
+    const int64_t *d_evoff;
+    double c1;
+    double *X, *Y;
+    uint32_t *nz_cur = nullptr, *nz_oth = nullptr;
+    int nz_iters = 0;
+    int64_t it = 0;
+
+    GroupIter(rwr_graph *g_, int G_, int tg_, const int32_t *seeds, const int64_t *evoff, double d)
+        : g(g_), G(G_), tg(tg_), d_seeds(seeds), d_evoff(evoff), c1(1 - d) /* Model.cs:84: (1 - dampingFactor) */,
+          X(g_->X.p), Y(g_->Y.p) {}
+
+    int32_t init()
+    {
+        const int32_t n = g->n;
+        hipStream_t s = g->stream;
+        const size_t elems = (size_t)tg * (size_t)n * G;
+        RWR_HIP(hipMemsetAsync(X, 0, elems * sizeof(double), s));
+        // frontier bitmaps for the first iterations (chunked SpMM only)
+        static const int nz_iters_env = [] { const char *e = getenv("RWR_NZ_ITERS"); return e ? atoi(e) : 3; }();
+        static const int spmm_variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
+        nz_iters = (G >= 8 && spmm_variant != 0) ? nz_iters_env : 0;
+        const size_t nzw = ((size_t)n + 31) / 32;
+        nz_cur = nz_iters > 0 ? g->d_nz.p : nullptr;
+        nz_oth = nz_iters > 0 ? g->d_nz.p + (size_t)tg * nzw : nullptr;
+        if (nz_cur) RWR_HIP(hipMemsetAsync(nz_cur, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_init_seeds, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, X, d_seeds, nz_cur);
+        RWR_HIP(hipGetLastError());
+        it = 0;
+        return RWR_OK;
+    }
+
+    int32_t step(EvPool &pool, std::vector<hipEvent_t> &spmm_ev, std::vector<hipEvent_t> &chain_ev)
+    {
+        const int32_t n = g->n;
+        hipStream_t s = g->stream, s2 = g->stream2;
+        const bool exact = g->opts.mode != RWR_MODE_FAST;
+        const bool prof = g->opts.profile != 0;
+        const size_t nzw = ((size_t)n + 31) / 32;
+        constexpr int GATE_SLOTS = 64;
+        static const int use_gate = [] { const char *e = getenv("RWR_GATE"); return e ? atoi(e) : 1; }();
+        static const int serial = [] { const char *e = getenv("RWR_CHAIN_SERIAL"); return e ? atoi(e) : 0; }();
+        unsigned int *gate_it = nullptr;
         const uint32_t *nz_in = (it < nz_iters) ? nz_cur : nullptr;
         uint32_t *nz_out = (it + 1 < nz_iters) ? nz_oth : nullptr;
         if (nz_out) RWR_HIP(hipMemsetAsync(nz_out, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
-        static const int serial = [] { const char *e = getenv("RWR_CHAIN_SERIAL"); return e ? atoi(e) : 0; }();
         if (exact && serial) s2 = s;
         if (exact) {
             // fork: the seed-row chain runs beside the SpMM on the second stream
@@ -675,12 +697,23 @@ int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, const
             RWR_DISPATCH_G(G, launch_restart_final<GG>(g, tg, Y, d_seeds, nz_out, s));
         }
         RWR_HIP(hipGetLastError());
-        double *t = X; X = Y; Y = t;   // Model.updateRanks (Model.cs:103-108)
+        { double *t = X; X = Y; Y = t; }   // Model.updateRanks (Model.cs:103-108)
         { uint32_t *tz = nz_cur; nz_cur = nz_oth; nz_oth = tz; }
         g->stats.spmm_launches += 1;
         g->stats.chain_launches += 1;
+        ++it;
+        return RWR_OK;
     }
-    *final_X = X;
+};
+
+int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, const int64_t *d_evoff, double d,
+                      int64_t n_iter, double **final_X, EvPool &pool, std::vector<hipEvent_t> &spmm_ev,
+                      std::vector<hipEvent_t> &chain_ev)
+{
+    GroupIter gi(g, G, tg, d_seeds, d_evoff, d);
+    RWR_TRY(gi.init());
+    for (int64_t it = 0; it < n_iter; ++it) RWR_TRY(gi.step(pool, spmm_ev, chain_ev));
+    *final_X = gi.X;
     return RWR_OK;
 }
 
@@ -841,29 +874,143 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
     return RWR_OK;
 }
 
-int32_t model_run_iters(rwr_graph *g, int32_t seed, double d, int64_t n_iter, double *rank_out)
+// ---- Model.run() / run(double) / global model (Model.cs:14-31, 52-66, 110-115) -------------------------------
+
+// sum over i of |a_i - b_i|  (checkConvergence, Model.cs:110-115) or of the restart addends of the global model;
+// deterministic two-level tree (the reference sums sequentially: tolerance-level difference)
+constexpr int RED_GRID = 256;
+__global__ __launch_bounds__(256) void k_l1_partial(const double *__restrict__ a, const double *__restrict__ b, int32_t n,
+                                                    double *__restrict__ part)
+{
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double x = a[i], y = b[i];
+        acc += (x > y) ? (x - y) : (y - x);                                  // Model.cs:113
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if ((int)threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void k_rr_partial(const double *__restrict__ x, const uint8_t *__restrict__ dangling,
+                                                    int32_t n, double c1, double *__restrict__ part)
+{
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double xi = x[i], rw = c1 * xi;
+        acc += dangling[i] ? xi : (xi - rw);                                 // Model.cs:91 / :97
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if ((int)threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ void k_sum_parts(const double *__restrict__ part, int nparts, double *__restrict__ out)
+{
+    double s = 0.0;
+    for (int b = 0; b < nparts; ++b) s += part[b];
+    *out = s;
+}
+__global__ void k_fill(double *__restrict__ x, int32_t n, double v)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+// global model: every node receives restart mass / n  (restart[r] = 1/n, Model.cs:29,92-93,96-97)
+__global__ void k_add_restart_share(double *__restrict__ y, int32_t n, const double *__restrict__ total, double inv_n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += *total * inv_n;
+}
+
+int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double value, double *rank_out,
+                  int64_t *iters_out)
 {
     const int32_t n = g->n;
-    if (seed < 0 || seed >= n) {
-        set_error("seed %d is outside [0, %d)", seed, n);
+    if (seed < -1 || seed >= n) {
+        set_error("seed %d is outside [0, %d) (and is not -1 = global model)", seed, n);
         return RWR_E_RANGE;
     }
-    // one seed, one lane per row: the rank vector is contiguous
+    // one model, one lane per row: the rank vector is contiguous
     const int G = 1;
     int TG = 1;
     RWR_TRY(ensure_workspace(g, G, 1, &TG));
+    hipStream_t s = g->stream;
     EvPool pool;
     std::vector<hipEvent_t> a, b;
+    static const int64_t max_iters = [] { const char *e = getenv("RWR_MAX_ITERS"); return e ? atoll(e) : (int64_t)1000000; }();
+    const bool by_count = run_mode == RWR_RUN_ITERATIONS;
+    // Model.cs:53: threshold = (1 / double.MaxValue) * n   (a subnormal-scale number: "until nothing changes")
+    const double threshold = run_mode == RWR_RUN_DEFAULT_THRESHOLD ? (1 / 1.7976931348623157e308) * n : value;
+    int64_t T = by_count ? (int64_t)value : max_iters;
+    if (T < 0) T = 0;
+    RWR_TRY(g->d_part.ensure(RED_GRID + 8));
+    double *part = g->d_part.p, *scalar = g->d_part.p + RED_GRID;
+    int64_t done = 0;
     double *Xf = nullptr;
-    RWR_TRY(upload_seed_slots(g, &seed, 1, 1, nullptr));
-    RWR_TRY(iterate_group(g, G, 1, g->d_seeds.p, g->d_evoff.p, d, n_iter, &Xf, pool, a, b));
-    RWR_HIP(hipMemcpyAsync(rank_out, Xf, sizeof(double) * n, hipMemcpyDeviceToHost, g->stream));
-    RWR_HIP(hipStreamSynchronize(g->stream));
-    RWR_HIP(hipStreamSynchronize(g->stream2));
-    if (g->opts.profile) {
-        RWR_TRY(drain_events(a, &g->stats.spmm_ms));
-        RWR_TRY(drain_events(b, &g->stats.chain_ms));
+
+    if (seed >= 0) {
+        RWR_TRY(upload_seed_slots(g, &seed, 1, 1, nullptr));
+        GroupIter gi(g, G, 1, g->d_seeds.p, g->d_evoff.p, d);
+        RWR_TRY(gi.init());
+        while (done < T) {
+            RWR_TRY(gi.step(pool, a, b));                                   // deliverRanks + updateRanks
+            ++done;
+            if (!by_count) {                                                // checkConvergence (Model.cs:58-65)
+                hipLaunchKernelGGL(k_l1_partial, dim3(RED_GRID), dim3(256), 0, s, gi.Y, gi.X, n, part);
+                hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(1), 0, s, part, RED_GRID, scalar);
+                double diff = 0;
+                RWR_HIP(hipMemcpyAsync(&diff, scalar, sizeof(double), hipMemcpyDeviceToHost, s));
+                RWR_HIP(hipStreamSynchronize(s));
+                if (diff < threshold) break;
+                a.clear(); b.clear(); pool.used = 0;                        // (synchronised above: safe to recycle)
+            }
+        }
+        Xf = gi.X;
+    } else {
+        // global model (Model.cs:14-31): rank = 1, restart = 1/n.  Every row receives the restart mass of every node,
+        // interleaved in node order in the reference; here: edge part in reference order + (tree-summed mass)/n.
+        // Tolerance parity only.
+        double *X = g->X.p, *Y = g->Y.p;
+        const double c1 = 1 - d, inv_n = 1.0 / n;
+        hipLaunchKernelGGL(k_fill, dim3(cdiv((size_t)n, 256)), dim3(256), 0, s, X, n, 1.0);
+        int32_t no_seed = -1;
+        RWR_HIP(hipMemcpyAsync(g->d_seeds.p, &no_seed, sizeof(int32_t), hipMemcpyHostToDevice, s));
+        while (done < T) {
+            hipLaunchKernelGGL(k_rr_partial, dim3(RED_GRID), dim3(256), 0, s, X, g->dangling.p, n, c1, part);
+            hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(1), 0, s, part, RED_GRID, scalar);
+            launch_spmm<1>(g, 1, X, Y, g->d_seeds.p, c1, 0, nullptr, nullptr, s);
+            hipLaunchKernelGGL(k_add_restart_share, dim3(cdiv((size_t)n, 256)), dim3(256), 0, s, Y, n, scalar, inv_n);
+            RWR_HIP(hipGetLastError());
+            { double *t = X; X = Y; Y = t; }
+            ++done;
+            if (!by_count) {
+                hipLaunchKernelGGL(k_l1_partial, dim3(RED_GRID), dim3(256), 0, s, Y, X, n, part);
+                hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(1), 0, s, part, RED_GRID, scalar);
+                double diff = 0;
+                RWR_HIP(hipMemcpyAsync(&diff, scalar, sizeof(double), hipMemcpyDeviceToHost, s));
+                RWR_HIP(hipStreamSynchronize(s));
+                if (diff < threshold) break;
+            }
+        }
+        Xf = X;
     }
+    if (!by_count && done >= max_iters) {
+        set_error("rwr_model_run: no convergence within %lld iterations (RWR_MAX_ITERS)", (long long)max_iters);
+        return RWR_E_UNSUPPORTED;
+    }
+    RWR_HIP(hipMemcpyAsync(rank_out, Xf, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipStreamSynchronize(s));
+    RWR_HIP(hipStreamSynchronize(g->stream2));
+    if (iters_out) *iters_out = done;
     return RWR_OK;
 }
 

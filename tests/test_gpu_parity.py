@@ -215,3 +215,49 @@ def test_structural_ties_keep_id_order(amd):
     bi, bs, bc = amd.Recommender(G).RecommendationBatch(np.array([1, 2, 0], dtype=np.int32), 0.15, 6, 10)
     oi, os_, oc = F.recommend_batch(np.array([1, 2, 0], dtype=np.int32), 0.15, 6, 10)
     assert (bi == oi).all() and (bits(bs) == bits(os_)).all() and (bc == oc).all()
+
+
+@pytest.mark.parametrize("case", SMALL[:3], ids=lambda c: f"g{c['seed']}")
+def test_model_threshold_and_default_run(amd, case):
+    """Model.run(double) / Model.run() (Model.cs:52-66,110-115): ranks bitwise (the kernels are the exact ones),
+    iteration count equal to the oracle's (the L1 distance is tree-summed on the GPU, sequential in the
+    reference: only a distance within rounding of the threshold could differ)."""
+    g = gg.random_graph(**case)
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g)
+    d = po.widen_float(0.15)
+    for seed in (0, case["n_users"] - 1):
+        for thr in (1e-3, 1e-9):
+            m = amd.Model(G, d, seed)
+            m.run(thr)
+            r, it = F.model_run(d, seed, 1, thr)
+            assert m.iterations == it
+            assert (bits(m.rank) == bits(r)).all()
+    # run(): threshold (1/double.MaxValue)*n -- iterate until the ranks stop changing at all
+    # (some graphs never reach an exact fixed point -- the ranks keep flipping in the last bit and the reference
+    # itself would loop forever; only graphs on which the oracle converges are compared)
+    r, it = F.model_run(d, 0, 2, 0.0, max_iter=20000)
+    if it < 20000:
+        m = amd.Model(G, d, 0)
+        m.run()
+        assert m.iterations == it and (bits(m.rank) == bits(r)).all()
+
+
+@pytest.mark.parametrize("case", SMALL[:2] + MEDIUM[:1], ids=lambda c: f"g{c['seed']}")
+def test_global_model_tolerance(amd, case):
+    """Global (non-personalised) model, Model.cs:14-31: tolerance parity only -- the reference
+    interleaves n restart addends into every row; the GPU adds the tree-summed mass / n once per row."""
+    g = gg.random_graph(**case)
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g)
+    n = len(g["node_id"])
+    for T in (1, 4, 10):
+        m = amd.Model(G, 0.15)
+        m.run(T)
+        r, _ = F.model_run(0.15, -1, 0, T, dense=(n < 500))
+        assert np.abs(m.rank - r).max() <= 1e-12 * max(1.0, np.abs(r).max())
+        assert abs(m.rank.sum() - n) < 1e-9 * n
+    m = amd.Model(G, 0.15)
+    m.run(1e-10)
+    r, it = F.model_run(0.15, -1, 1, 1e-10)
+    assert abs(m.iterations - it) <= 1 and np.abs(m.rank - r).max() <= 1e-9
