@@ -168,6 +168,26 @@ int32_t rwr_recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, float
 int32_t rwr_model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double value,
                       double *rank_out, int64_t *iters_out);
 
+/* ---- row-partitioned mode (graphs beyond one GPU; BASELINE.json config 5) ------------
+ * An ADDITION: the reference has no distributed mode.  The transition matrix is partitioned by SOURCE rows
+ * (the reference's native layout: graph[i] = out-links of i, Graph.cs:43): rank r owns the contiguous node slab
+ * [slab_lo, slab_hi) and creates its rwr_graph from the FULL node arrays but with out-links only for its own
+ * rows (rowptr flat outside the slab).  Every rank keeps the full rank matrix x[n][G] (G = tile width,
+ * K <= 64 seeds); one power-iteration step is
+ *     rwr_part_local_step    y = (1-d) * P_slab^T x   over ALL n rows,  r[k] = restart mass of the slab's rows
+ *     (caller)               all-reduce(sum) of y and r over the ranks  -- RCCL over xGMI, torch.distributed
+ *     rwr_part_finish_step   y[seed_k][k] += r[k]      (Model.cs:91-93,96-97)
+ * after which y is the next x.  dev_* are DEVICE pointers owned by the caller (n*G, n*G and G doubles).
+ * Partial sums re-associate across ranks: parity with the single-GPU result is to tolerance (scores
+ * within 1e-6; identical top-k lists in the tests), never bitwise.  rwr_part_rank ranks the seeds whose row
+ * this rank owns (only the owner holds the seed's raw LIKE links for the exclusion list,
+ * Recommender.cs:20-24) and reports counts[k] = -1 for the others. */
+int32_t rwr_part_begin(rwr_graph *g, int32_t slab_lo, int32_t slab_hi, const int32_t *seeds, int32_t K, double d,
+                       void *dev_x, int32_t *tile_seeds_out);
+int32_t rwr_part_local_step(rwr_graph *g, const void *dev_x, void *dev_y, void *dev_r);
+int32_t rwr_part_finish_step(rwr_graph *g, void *dev_y, const void *dev_r);
+int32_t rwr_part_rank(rwr_graph *g, void *dev_x, int32_t top_n, int64_t *ids, double *scores, int32_t *counts);
+
 /* ---- measurement ---------------------------------------------------------------------- */
 int32_t rwr_get_stats(rwr_graph *g, rwr_stats *out);
 int32_t rwr_reset_stats(rwr_graph *g);

@@ -20,6 +20,7 @@ EXPORTS = [
     "rwr_version", "rwr_device_count", "rwr_last_error",
     "rwr_graph_create", "rwr_graph_destroy", "rwr_graph_size", "rwr_graph_get_normalized",
     "rwr_recommend", "rwr_recommend_batch", "rwr_model_run",
+    "rwr_part_begin", "rwr_part_local_step", "rwr_part_finish_step", "rwr_part_rank",
     "rwr_get_stats", "rwr_reset_stats",
 ]
 
@@ -79,6 +80,15 @@ def load():
     lib.rwr_model_run.restype = C.c_int32
     lib.rwr_model_run.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_double, p(C.c_double),
                                   p(C.c_int64)]
+    lib.rwr_part_begin.restype = C.c_int32
+    lib.rwr_part_begin.argtypes = [C.c_void_p, C.c_int32, C.c_int32, p(C.c_int32), C.c_int32, C.c_double, C.c_void_p,
+                                   p(C.c_int32)]
+    lib.rwr_part_local_step.restype = C.c_int32
+    lib.rwr_part_local_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rwr_part_finish_step.restype = C.c_int32
+    lib.rwr_part_finish_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rwr_part_rank.restype = C.c_int32
+    lib.rwr_part_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, p(C.c_int64), p(C.c_double), p(C.c_int32)]
     lib.rwr_get_stats.restype = C.c_int32
     lib.rwr_get_stats.argtypes = [C.c_void_p, p(rwr_stats)]
     lib.rwr_reset_stats.restype = C.c_int32

@@ -237,6 +237,39 @@ int32_t rwr_model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, do
     return RWR_OK;
 }
 
+int32_t rwr_part_begin(rwr_graph *g, int32_t slab_lo, int32_t slab_hi, const int32_t *seeds, int32_t K, double d,
+                       void *dev_x, int32_t *tile_seeds_out)
+{
+    g_err[0] = 0;
+    if (!g || !seeds || !dev_x) { set_error("rwr_part_begin: NULL argument"); return RWR_E_INVALID; }
+    RWR_TRY(bind_device(g));
+    return part_begin(g, slab_lo, slab_hi, seeds, K, d, (double *)dev_x, tile_seeds_out);
+}
+
+int32_t rwr_part_local_step(rwr_graph *g, const void *dev_x, void *dev_y, void *dev_r)
+{
+    g_err[0] = 0;
+    if (!g || !dev_x || !dev_y || !dev_r) { set_error("rwr_part_local_step: NULL argument"); return RWR_E_INVALID; }
+    RWR_TRY(bind_device(g));
+    return part_local_step(g, (const double *)dev_x, (double *)dev_y, (double *)dev_r);
+}
+
+int32_t rwr_part_finish_step(rwr_graph *g, void *dev_y, const void *dev_r)
+{
+    g_err[0] = 0;
+    if (!g || !dev_y || !dev_r) { set_error("rwr_part_finish_step: NULL argument"); return RWR_E_INVALID; }
+    RWR_TRY(bind_device(g));
+    return part_finish_step(g, (double *)dev_y, (const double *)dev_r);
+}
+
+int32_t rwr_part_rank(rwr_graph *g, void *dev_x, int32_t top_n, int64_t *ids, double *scores, int32_t *counts)
+{
+    g_err[0] = 0;
+    if (!g || !dev_x || !ids || !scores || !counts) { set_error("rwr_part_rank: NULL argument"); return RWR_E_INVALID; }
+    RWR_TRY(bind_device(g));
+    return part_rank(g, (double *)dev_x, top_n, ids, scores, counts);
+}
+
 int32_t rwr_get_stats(rwr_graph *g, rwr_stats *out)
 {
     if (!g || !out) { set_error("rwr_get_stats: NULL argument"); return RWR_E_INVALID; }

@@ -50,6 +50,11 @@ struct rwr_graph {
     rwr::DevBuf<double> d_out_score;
     rwr::DevBuf<int32_t> d_counts;
 
+    // row-partitioned mode (rwr_part_*)
+    int32_t part_lo = 0, part_hi = 0, part_G = 0, part_K = 0;
+    double part_c1 = 0;
+    std::vector<int32_t> part_seeds;
+
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;   // profiling pairs
@@ -66,6 +71,11 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
 // (mode 0: top-k into host arrays; mode 1: full rank vector of one seed)
 int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d, int32_t n_iter, int32_t top_n,
                         int64_t *ids, double *scores, int32_t *counts, int64_t row_stride);
+int32_t part_begin(rwr_graph *g, int32_t lo, int32_t hi, const int32_t *seeds, int32_t K, double d, double *x,
+                   int32_t *G_out);
+int32_t part_local_step(rwr_graph *g, const double *x, double *y, double *r);
+int32_t part_finish_step(rwr_graph *g, double *y, const double *r);
+int32_t part_rank(rwr_graph *g, double *x, int32_t top_n, int64_t *ids, double *scores, int32_t *counts);
 int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double value, double *rank_out,
                   int64_t *iters_out);
 

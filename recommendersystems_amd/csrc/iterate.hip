@@ -1014,4 +1014,134 @@ int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double
     return RWR_OK;
 }
 
+// ---- row-partitioned mode (include/rwr.h: rwr_part_*) -----------------------------------------------------------
+
+// restart mass of the slab's rows only: r[k] = sum over i in [lo, hi) of (dangling_i ? x_i : x_i - (1-d) x_i)
+template <int G>
+__global__ __launch_bounds__(RP_BLOCK) void k_slab_restart_partial(int32_t lo, int32_t hi,
+                                                                   const uint8_t *__restrict__ dangling,
+                                                                   const double *__restrict__ x,
+                                                                   double *__restrict__ part, double c1)
+{
+    constexpr int RL = RP_BLOCK / G;
+    __shared__ double sh[RP_BLOCK];
+    const int k = threadIdx.x % G, rl = threadIdx.x / G;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)lo + (int64_t)blockIdx.x * RL + rl; i < hi; i += (int64_t)gridDim.x * RL) {
+        const double xi = x[(size_t)i * G + k];
+        const double rw = c1 * xi;
+        acc += dangling[i] ? xi : (xi - rw);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int half = RL / 2; half >= 1; half >>= 1) {
+        if (rl < half) sh[threadIdx.x] += sh[threadIdx.x + half * G];
+        __syncthreads();
+    }
+    if (rl == 0) part[(size_t)blockIdx.x * G + k] = sh[k];
+}
+__global__ void k_slab_restart_final(int G, int nblk, const double *__restrict__ part, double *__restrict__ r)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= G) return;
+    double R = 0.0;
+    for (int b = 0; b < nblk; ++b) R += part[(size_t)b * G + k];
+    r[k] = R;
+}
+__global__ void k_part_add_restart(int G, double *__restrict__ y, const double *__restrict__ r,
+                                   const int32_t *__restrict__ seeds)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= G) return;
+    const int32_t s = seeds[k];
+    if (s >= 0) y[(size_t)s * G + k] += r[k];
+}
+
+int32_t part_begin(rwr_graph *g, int32_t lo, int32_t hi, const int32_t *seeds, int32_t K, double d, double *x,
+                   int32_t *G_out)
+{
+    const int32_t n = g->n;
+    if (lo < 0 || hi > n || lo > hi) { set_error("rwr_part_begin: bad slab [%d, %d)", lo, hi); return RWR_E_RANGE; }
+    if (K < 1 || K > 64) { set_error("rwr_part_begin: K must be 1..64 in row-partitioned mode"); return RWR_E_UNSUPPORTED; }
+    for (int32_t k = 0; k < K; ++k)
+        if (seeds[k] < 0 || seeds[k] >= n) { set_error("seed %d is outside [0, %d)", seeds[k], n); return RWR_E_RANGE; }
+    int G = 1;
+    while (G < K) G <<= 1;
+    g->part_lo = lo; g->part_hi = hi; g->part_G = G; g->part_K = K; g->part_c1 = 1 - d;
+    g->part_seeds.assign((size_t)G, -1);
+    for (int32_t k = 0; k < K; ++k) g->part_seeds[k] = seeds[k];
+    RWR_TRY(g->d_seeds.ensure(G));
+    RWR_TRY(g->d_part.ensure((size_t)RP_GRID * G));
+    RWR_HIP(hipMemcpy(g->d_seeds.p, g->part_seeds.data(), G * sizeof(int32_t), hipMemcpyHostToDevice));
+    hipStream_t s = g->stream;
+    RWR_HIP(hipMemsetAsync(x, 0, (size_t)n * G * sizeof(double), s));
+    hipLaunchKernelGGL(k_init_seeds, dim3(1), dim3(64), 0, s, n, 1, G, x, g->d_seeds.p, (uint32_t *)nullptr);
+    RWR_HIP(hipGetLastError());
+    RWR_HIP(hipStreamSynchronize(s));
+    if (G_out) *G_out = G;
+    return RWR_OK;
+}
+
+int32_t part_local_step(rwr_graph *g, const double *x, double *y, double *r)
+{
+    const int G = g->part_G;
+    if (G == 0) { set_error("rwr_part_local_step: rwr_part_begin has not been called"); return RWR_E_INVALID; }
+    hipStream_t s = g->stream;
+    const double c1 = g->part_c1;
+    RWR_DISPATCH_G(G, hipLaunchKernelGGL(k_slab_restart_partial<GG>, dim3(RP_GRID), dim3(RP_BLOCK), 0, s, g->part_lo,
+                                         g->part_hi, g->dangling.p, x, g->d_part.p, c1));
+    hipLaunchKernelGGL(k_slab_restart_final, dim3(1), dim3(64), 0, s, G, RP_GRID, g->d_part.p, r);
+    // the graph holds only this slab's out-links, so the in-lists contain only in-slab sources
+    RWR_DISPATCH_G(G, launch_spmm<GG>(g, 1, x, y, g->d_seeds.p, c1, 0, nullptr, nullptr, s));
+    RWR_HIP(hipGetLastError());
+    RWR_HIP(hipStreamSynchronize(s));
+    return RWR_OK;
+}
+
+int32_t part_finish_step(rwr_graph *g, double *y, const double *r)
+{
+    const int G = g->part_G;
+    if (G == 0) { set_error("rwr_part_finish_step: rwr_part_begin has not been called"); return RWR_E_INVALID; }
+    hipLaunchKernelGGL(k_part_add_restart, dim3(1), dim3(64), 0, g->stream, G, y, r, g->d_seeds.p);
+    RWR_HIP(hipGetLastError());
+    RWR_HIP(hipStreamSynchronize(g->stream));
+    return RWR_OK;
+}
+
+int32_t part_rank(rwr_graph *g, double *x, int32_t top_n, int64_t *ids, double *scores, int32_t *counts)
+{
+    const int G = g->part_G, K = g->part_K;
+    if (G == 0) { set_error("rwr_part_rank: rwr_part_begin has not been called"); return RWR_E_INVALID; }
+    if (top_n < 1 || top_n > rank_select_max_k()) {
+        set_error("rwr_part_rank: top_n must be 1..%d", rank_select_max_k());
+        return RWR_E_UNSUPPORTED;
+    }
+    hipStream_t s = g->stream;
+    // only the owner of a seed's row has its raw LIKE links (exclusion list): rank those, report -1 for the rest
+    std::vector<int32_t> own((size_t)G, -1), slot_k((size_t)G, -1);
+    for (int k = 0; k < K; ++k)
+        if (g->part_seeds[k] >= g->part_lo && g->part_seeds[k] < g->part_hi) { own[k] = g->part_seeds[k]; slot_k[k] = k; }
+    DevBuf<int32_t> d_own;
+    RWR_TRY(d_own.alloc(G));
+    RWR_TRY(g->d_slot_k.ensure(G));
+    RWR_HIP(hipMemcpy(d_own.p, own.data(), G * sizeof(int32_t), hipMemcpyHostToDevice));
+    RWR_HIP(hipMemcpy(g->d_slot_k.p, slot_k.data(), G * sizeof(int32_t), hipMemcpyHostToDevice));
+    const size_t out_elems = (size_t)G * top_n;
+    RWR_TRY(g->d_out_id.ensure(out_elems));
+    RWR_TRY(g->d_out_score.ensure(out_elems));
+    RWR_TRY(g->d_counts.ensure(G));
+    RWR_HIP(hipMemsetAsync(g->d_out_id.p, 0, out_elems * sizeof(int64_t), s));
+    RWR_HIP(hipMemsetAsync(g->d_out_score.p, 0, out_elems * sizeof(double), s));
+    RWR_HIP(hipMemsetAsync(g->d_counts.p, 0, G * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_exclude, dim3(1), dim3(64), 0, s, g->n, 1, G, g->rowptr.p, g->dst.p, g->etype.p, x, d_own.p);
+    RWR_TRY(rank_group_select(g, G, 1, g->d_slot_k.p, top_n, x, d_own.p, s));
+    std::vector<int32_t> hc((size_t)G);
+    RWR_HIP(hipMemcpyAsync(hc.data(), g->d_counts.p, G * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipMemcpyAsync(ids, g->d_out_id.p, (size_t)K * top_n * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipMemcpyAsync(scores, g->d_out_score.p, (size_t)K * top_n * sizeof(double), hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < K; ++k) counts[k] = own[k] >= 0 ? hc[k] : -1;
+    return RWR_OK;
+}
+
 }  // namespace rwr

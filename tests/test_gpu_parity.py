@@ -261,3 +261,48 @@ def test_global_model_tolerance(amd, case):
     m.run(1e-10)
     r, it = F.model_run(0.15, -1, 1, 1e-10)
     assert abs(m.iterations - it) <= 1 and np.abs(m.rank - r).max() <= 1e-9
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_row_partitioned_logical_ranks(amd, world):
+    """BASELINE config 5 on ONE device: `world` logical ranks, each with the HIP slab backend (rwr_part_*),
+    partials summed in rank order in place of the RCCL all-reduce.  Tolerance parity (partial sums re-associate):
+    identical top-k lists, scores within 1e-9 of the oracle."""
+    import torch
+    from recommendersystems_amd import partitioned as pt
+    g = gg.random_graph(51, n_users=500, n_items=1800, n_likes=15000, n_etc=10, n_friend=500, n_mention=300,
+                        n_author=200)
+    F = FlatGraph(**g)
+    seeds = np.array([0, 7, 123, 250, 499], dtype=np.int32)
+    bounds = pt.slab_bounds(g["rowptr"], world)
+    bes = [pt.HipSlabBackend(pt.slab_graph(g, int(bounds[r]), int(bounds[r + 1])), int(bounds[r]), int(bounds[r + 1]))
+           for r in range(world)]
+    d = float(np.float32(0.15))
+    state = [be.begin(seeds, d) for be in bes]
+    for _ in range(10):
+        for be, (x, y, r) in zip(bes, state):
+            be.local_step(x, y, r)
+        ysum = torch.stack([st[1] for st in state]).sum(0)       # stands in for all-reduce(sum)
+        rsum = torch.stack([st[2] for st in state]).sum(0)
+        for st in state:
+            st[1].copy_(ysum)
+            st[2].copy_(rsum)
+        new_state = []
+        for be, (x, y, r) in zip(bes, state):
+            be.finish_step(y, r)
+            new_state.append((y, x, r))
+        state = new_state
+    oi, os_, oc = F.recommend_batch(seeds, 0.15, 10, 20)
+    ids = np.zeros_like(oi); sc = np.zeros_like(os_); cnt = np.zeros_like(oc); owners = np.zeros(len(seeds), dtype=int)
+    for be, (x, y, r) in zip(bes, state):
+        i, s, c = be.rank(x, 20)
+        own = c >= 0
+        owners += own
+        ids[own], sc[own], cnt[own] = i[own], s[own], c[own]
+    assert (owners == 1).all()
+    assert (cnt == oc).all() and (ids == oi).all()
+    assert np.abs(sc - os_).max() <= 1e-9
+    if world == 1:   # the driver class itself, world size 1 (no process group needed)
+        pr = pt.PartitionedRecommender(g)
+        i2, s2, c2 = pr.RecommendationBatch(seeds, 0.15, 10, 20)
+        assert (i2 == oi).all() and (c2 == oc).all() and np.abs(s2 - os_).max() <= 1e-9

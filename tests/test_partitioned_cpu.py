@@ -1,0 +1,89 @@
+"""N > 1 host path on CPU: world_size-2 gloo processes run the seed-sharded gather and the row-partitioned
+iteration (all-reduce exchange per step) with a numpy compute stand-in, and compare with the oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle.c_oracle import FlatGraph
+from recommendersystems_amd import partitioned as pt
+from tests import graphgen as gg
+
+CASE = dict(seed=41, n_users=60, n_items=200, n_likes=1500, n_etc=4, n_friend=80, n_mention=60, n_author=30)
+
+
+def test_shard_and_slab_bounds():
+    assert [pt.shard_bounds(10, 3, r) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    assert [pt.shard_bounds(2, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    g = gg.random_graph(**CASE)
+    for world in (1, 2, 3, 8):
+        b = pt.slab_bounds(g["rowptr"], world)
+        assert b[0] == 0 and b[-1] == len(g["node_id"]) and (np.diff(b) >= 0).all() and len(b) == world + 1
+        tot = 0
+        for r in range(world):
+            lg = pt.slab_graph(g, int(b[r]), int(b[r + 1]))
+            assert len(lg["rowptr"]) == len(g["rowptr"])
+            tot += len(lg["dst"])
+            # rows inside the slab keep their links in list order, rows outside have none
+            for i in (int(b[r]), int(b[r + 1]) - 1):
+                if b[r] < b[r + 1]:
+                    assert (lg["dst"][lg["rowptr"][i]:lg["rowptr"][i + 1]] == g["dst"][g["rowptr"][i]:g["rowptr"][i + 1]]).all()
+        assert tot == len(g["dst"])
+        if world > 1:   # balanced by links
+            sizes = [g["rowptr"][b[r + 1]] - g["rowptr"][b[r]] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 2 * np.diff(g["rowptr"]).max() + 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.slab_double import NumpySlabBackend
+        g = gg.random_graph(**CASE)
+        F = FlatGraph(**g)
+        seeds = np.array([0, 3, 17, 41, 59], dtype=np.int32)
+        # (1) row-partitioned iteration with the all-reduce exchange
+        pr = pt.PartitionedRecommender(g, rank=rank, world=world, backend_factory=NumpySlabBackend)
+        ids, sc, cnt = pr.RecommendationBatch(seeds, 0.15, 10, 12)
+        oi, os_, oc = F.recommend_batch(seeds, 0.15, 10, 12)
+        ok1 = bool((cnt == oc).all() and (ids == oi).all() and np.abs(sc - os_).max() <= 1e-9)
+        # (2) seed-sharded batch: every rank computes its block (oracle as the stand-in compute), then gathers
+        all_seeds = np.arange(0, 60, 3, dtype=np.int32)
+        lo, hi = pt.shard_bounds(len(all_seeds), world, rank)
+        li, ls, lc = F.recommend_batch(all_seeds[lo:hi], 0.15, 6, 7)
+        fi, fs, fc = pt.gather_seed_shards(li, ls, lc, len(all_seeds))
+        gi, gs, gc = F.recommend_batch(all_seeds, 0.15, 6, 7)
+        ok2 = bool((fi == gi).all() and (fs.view(np.uint64) == gs.view(np.uint64)).all() and (fc == gc).all())
+        q.put((rank, ok1, ok2, float(np.abs(sc - os_).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_multi_rank(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    for rank, ok1, ok2, err in res:
+        assert ok1, (rank, "row-partitioned result differs from the oracle", err)
+        assert ok2, (rank, "seed-sharded gather differs from the oracle")
