@@ -146,6 +146,32 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
                 }
             }
             const int wlo = __double2loint(my_w), whi = __double2hiint(my_w);
+            if (CHECK) {
+                // sparse frontier: entries whose source row is all-zero add +0.0 -- skip them wholesale.  `um` is
+                // the union over the wave's row groups of the chunk positions that are live in SOME group.
+                const unsigned long long lm = __ballot(k < cnt && my_idx >= 0);
+                unsigned long long um = lm;
+                if (G < 64) {
+#pragma unroll
+                    for (int sh = G; sh < 64; sh <<= 1) um |= um >> sh;
+                    um &= (1ull << (G & 63)) - 1ull;
+                }
+                if (__popcll(um) <= 4) {
+                    while (um) {                                  // few live entries: take them one by one, in order
+                        const int t = __builtin_ctzll(um);
+                        um &= um - 1;
+                        const int idx = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), my_idx);
+                        const int lo = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), wlo);
+                        const int hi = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), whi);
+                        if (t < cnt && idx >= 0) {
+                            const double rw = c1 * X[(size_t)idx * G + k];   // Model.cs:84
+                            acc += rw * __hiloint2double(hi, lo);             // Model.cs:87
+                        }
+                    }
+                    p += cnt;
+                    continue;
+                }
+            }
             double xv[CH], wv[CH];
 #pragma unroll
             for (int t = 0; t < CH; ++t) {
@@ -608,8 +634,10 @@ static int resolve_G(const rwr_graph *g, int32_t K)
 {
     int G = g->opts.tile_seeds;
     if (G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64) return G;
+    // 32 seeds per tile (256-byte rows) measured best on the 100M-link graph: half the matrix re-streaming and
+    // half the per-entry instruction work of 16, while 64 gains nothing more and lengthens the seed-row chain
     int want = 1;
-    while (want < K && want < 16) want <<= 1;
+    while (want < K && want < 32) want <<= 1;
     return want;
 }
 

@@ -139,17 +139,30 @@ __global__ __launch_bounds__(256) void k_sel_hist(int32_t n, int32_t n_items, co
     const int32_t q0 = blockIdx.x * SEL_ROWS_PER_BLOCK;
     const int32_t q1 = (q0 + SEL_ROWS_PER_BLOCK < n_items) ? q0 + SEL_ROWS_PER_BLOCK : n_items;
     if (!my.done) {
-        for (int32_t q = q0 + rl; q < q1; q += RL) {
-            const int32_t row = item_rows[q];
-            const double s = x[(size_t)row * G + k];
-            if (!(s >= 0.0)) continue;                       // excluded (Recommender.cs:29)
-            const uint64_t hi = f64_orderable(s);
-            uint64_t lo = 0;
-            if (level >= 8) lo = i64_orderable(node_id[row]);
-            if (sel_cmp(hi, lo, my) != 0) continue;
-            const unsigned digit = (level < 8) ? (unsigned)(hi >> (56 - 8 * level)) & 255u
-                                               : (unsigned)(lo >> (56 - 8 * (level - 8))) & 255u;
-            atomicAdd(&h[k][digit], 1u);
+        // 4 rows per trip: four independent (row index -> score) load chains in flight per thread
+        for (int32_t qb = q0 + rl; qb < q1; qb += 4 * RL) {
+            int32_t row[4];
+            double sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int32_t q = qb + u * RL;
+                row[u] = item_rows[q < q1 ? q : q1 - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sv[u] = x[(size_t)row[u] * G + k];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (qb + u * RL >= q1) continue;
+                const double s = sv[u];
+                if (!(s >= 0.0)) continue;                       // excluded (Recommender.cs:29)
+                const uint64_t hi = f64_orderable(s);
+                uint64_t lo = 0;
+                if (level >= 8) lo = i64_orderable(node_id[row[u]]);
+                if (sel_cmp(hi, lo, my) != 0) continue;
+                const unsigned digit = (level < 8) ? (unsigned)(hi >> (56 - 8 * level)) & 255u
+                                                   : (unsigned)(lo >> (56 - 8 * (level - 8))) & 255u;
+                atomicAdd(&h[k][digit], 1u);
+            }
         }
     }
     __syncthreads();
@@ -216,16 +229,28 @@ __global__ __launch_bounds__(256) void k_sel_collect(int32_t n, int32_t n_items,
     const double *x = X + (size_t)tile * (size_t)n * G;
     const int32_t q0 = blockIdx.x * SEL_ROWS_PER_BLOCK;
     const int32_t q1 = (q0 + SEL_ROWS_PER_BLOCK < n_items) ? q0 + SEL_ROWS_PER_BLOCK : n_items;
-    for (int32_t q = q0 + rl; q < q1; q += RL) {
-        const int32_t row = item_rows[q];
-        const double s = x[(size_t)row * G + k];
-        if (!(s >= 0.0)) continue;
-        const uint64_t hi = f64_orderable(s);
-        if (my.nbits > 0 && my.nbits <= 64 && (hi >> (64 - my.nbits)) < my.ph) continue;   // cheap reject
-        const uint64_t lo = i64_orderable(node_id[row]);
-        if (sel_cmp(hi, lo, my) < 0) continue;
-        const int slot = atomicAdd(&st[tile * G + k].cand_cnt, 1);
-        if (slot < SEL_SLOTS) cand[((size_t)tile * G + k) * SEL_SLOTS + slot] = SelCand{hi, lo};
+    for (int32_t qb = q0 + rl; qb < q1; qb += 4 * RL) {
+        int32_t row[4];
+        double sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int32_t q = qb + u * RL;
+            row[u] = item_rows[q < q1 ? q : q1 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sv[u] = x[(size_t)row[u] * G + k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (qb + u * RL >= q1) continue;
+            const double s = sv[u];
+            if (!(s >= 0.0)) continue;
+            const uint64_t hi = f64_orderable(s);
+            if (my.nbits > 0 && my.nbits <= 64 && (hi >> (64 - my.nbits)) < my.ph) continue;   // cheap reject
+            const uint64_t lo = i64_orderable(node_id[row[u]]);
+            if (sel_cmp(hi, lo, my) < 0) continue;
+            const int slot = atomicAdd(&st[tile * G + k].cand_cnt, 1);
+            if (slot < SEL_SLOTS) cand[((size_t)tile * G + k) * SEL_SLOTS + slot] = SelCand{hi, lo};
+        }
     }
 }
 
