@@ -636,8 +636,10 @@ static int resolve_G(const rwr_graph *g, int32_t K)
     if (G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64) return G;
     // 32 seeds per tile (256-byte rows) measured best on the 100M-link graph: half the matrix re-streaming and
     // half the per-entry instruction work of 16, while 64 gains nothing more and lengthens the seed-row chain
+    // (on the 20M-link graph 16 is a little faster: the ranking stage scales with the tile width)
+    const int cap = (g->n >= 2000000) ? 32 : 16;
     int want = 1;
-    while (want < K && want < 32) want <<= 1;
+    while (want < K && want < cap) want <<= 1;
     return want;
 }
 
