@@ -152,6 +152,14 @@ int32_t rwr_graph_get_normalized(rwr_graph *g, double *w_out /* nnz_raw */, uint
 int32_t rwr_recommend(rwr_graph *g, int32_t seed, float d, int32_t n_iter, int32_t top_n,
                       int64_t *out_id, double *out_score, int64_t *inout_count);
 
+/* Recommendation + the evaluation the harness runs on its result (TweetRecommender/Experiment.cs:109,121-128):
+ * walks the FULL ranked list and returns  n_hits = #{ranked ids in test_ids}  and
+ * sum_precision = sum over hits, in rank order, of (double)hitsSoFar / (position + 1)  -- the harness then reports
+ * n_hits and sum_precision / n_hits (Experiment.cs:131-138).  The list itself never leaves the device.
+ * list_len (optional) receives the length of the ranked list. */
+int32_t rwr_recommend_eval(rwr_graph *g, int32_t seed, float d, int32_t n_iter, const int64_t *test_ids,
+                           int64_t n_test, int64_t *n_hits, double *sum_precision, int64_t *list_len);
+
 /* Batch entry (an addition: the reference creates a fresh Model per call, Recommender.cs:16,
  * so seeds are independent and batching is semantically free).  top_n must be >= 1.
  * ids/scores are K x top_n row-major; counts[k] = entries valid in row k (the rest of the

@@ -106,5 +106,18 @@ class FlatGraph:
         return ids, sc, counts
 
 
+def evaluate(ranked_ids, test_ids):
+    """Experiment.cs:121-128 -> (nHits, sumPrecision)."""
+    r = np.ascontiguousarray(ranked_ids, dtype=np.int64)
+    t = np.ascontiguousarray(test_ids, dtype=np.int64)
+    hits = C.c_int64(0)
+    sp = C.c_double(0.0)
+    rc = lib().rwr_oracle_evaluate(_p(r, C.c_int64), C.c_int64(len(r)), _p(t, C.c_int64), C.c_int64(len(t)),
+                                   C.byref(hits), C.byref(sp))
+    if rc != 0:
+        raise ValueError("rwr_oracle_evaluate failed")
+    return int(hits.value), float(sp.value)
+
+
 def max_threads() -> int:
     return int(lib().rwr_oracle_max_threads())

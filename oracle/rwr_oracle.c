@@ -206,6 +206,34 @@ int rwr_oracle_recommend_batch(int32_t n, const int64_t *node_id, const uint8_t 
     return bad ? -1 : 0;
 }
 
+static int cmp_i64(const void *a, const void *b)
+{
+    int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+    return (x > y) - (x < y);
+}
+
+/* Experiment.cs:121-128: hits and running-precision sum of a ranked id list against the test set. */
+int rwr_oracle_evaluate(const int64_t *ranked_ids, int64_t count, const int64_t *test_ids, int64_t n_test,
+                        int64_t *hits_out, double *sum_precision_out)
+{
+    int64_t *ts = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_test > 0 ? n_test : 1));
+    if (!ts) return -1;
+    memcpy(ts, test_ids, sizeof(int64_t) * (size_t)n_test);
+    qsort(ts, (size_t)n_test, sizeof(int64_t), cmp_i64);
+    int64_t nHits = 0;
+    double sumPrecision = 0;
+    for (int64_t i = 0; i < count; i++) {                                   /* :123 */
+        if (bsearch(&ranked_ids[i], ts, (size_t)n_test, sizeof(int64_t), cmp_i64)) {   /* :124 testSet.Contains */
+            nHits += 1;
+            sumPrecision += (double)nHits / (double)(i + 1);                /* :126 */
+        }
+    }
+    free(ts);
+    *hits_out = nHits;
+    *sum_precision_out = sumPrecision;
+    return 0;
+}
+
 int rwr_oracle_max_threads(void)
 {
 #ifdef _OPENMP

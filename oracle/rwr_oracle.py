@@ -213,6 +213,18 @@ class Recommender:
         return recommendation
 
 
+def evaluate(recommendation, testSet):
+    """TweetRecommender/Experiment.cs:121-128: hits and the running-precision sum over the FULL ranked list.
+    Returns (nHits, sumPrecision); the harness reports nHits and sumPrecision / nHits (:131-138)."""
+    nHits = 0
+    sumPrecision = 0.0
+    for i in range(len(recommendation)):                      # :123
+        if recommendation[i][0] in testSet:                   # :124
+            nHits += 1
+            sumPrecision += float(nHits) / (i + 1)            # :126  (double)nHits / (i + 1)
+    return nHits, sumPrecision
+
+
 # ---------------------------------------------------------------------------
 # helpers shared by tests: flat (CSR) <-> dictionary form, hex encoding
 # ---------------------------------------------------------------------------

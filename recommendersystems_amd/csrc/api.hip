@@ -1,6 +1,7 @@
 // C-ABI entry points of librwr (include/rwr.h).  No CPU fallback anywhere: without a
 // usable gfx950 device every compute entry fails with RWR_E_NO_DEVICE.
 #include <stdarg.h>
+#include <algorithm>
 #include <stdlib.h>
 #include <string.h>
 
@@ -220,6 +221,33 @@ int32_t rwr_recommend(rwr_graph *g, int32_t seed, float d, int32_t n_iter, int32
         memcpy(out_score, hsc.data(), sizeof(double) * (size_t)cnt);
     }
     *inout_count = cnt;
+    return RWR_OK;
+}
+
+int32_t rwr_recommend_eval(rwr_graph *g, int32_t seed, float d, int32_t n_iter, const int64_t *test_ids,
+                           int64_t n_test, int64_t *n_hits, double *sum_precision, int64_t *list_len)
+{
+    g_err[0] = 0;
+    if (!g || !n_hits || !sum_precision || (n_test > 0 && !test_ids) || n_test < 0) {
+        set_error("rwr_recommend_eval: bad argument");
+        return RWR_E_INVALID;
+    }
+    if (seed < 0 || seed >= g->n) { set_error("seed %d is outside [0, %d)", seed, g->n); return RWR_E_RANGE; }
+    if (n_test > 0x7FFFFFFF) { set_error("rwr_recommend_eval: test set too large"); return RWR_E_UNSUPPORTED; }
+    if (n_iter < 0) n_iter = 0;
+    RWR_TRY(bind_device(g));
+    *n_hits = 0;
+    *sum_precision = 0.0;
+    if (list_len) *list_len = 0;
+    const int32_t width = g->n_items;
+    if (width == 0) return RWR_OK;
+    int32_t cnt = 0;
+    RWR_TRY(recommend_batch(g, &seed, 1, (double)d, n_iter, width, nullptr, nullptr, &cnt, width));
+    std::vector<int64_t> ts(test_ids, test_ids + n_test);
+    std::sort(ts.begin(), ts.end());
+    ts.erase(std::unique(ts.begin(), ts.end()), ts.end());     // HashSet<long>
+    RWR_TRY(eval_ranked(g, cnt, ts.data(), (int64_t)ts.size(), n_hits, sum_precision));
+    if (list_len) *list_len = cnt;
     return RWR_OK;
 }
 

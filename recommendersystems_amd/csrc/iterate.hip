@@ -883,11 +883,13 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
     // results: K x top_n (device rows are top_n wide; host rows are row_stride wide)
     std::vector<int32_t> hc((size_t)ntiles * G);
     RWR_HIP(hipMemcpyAsync(hc.data(), g->d_counts.p, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    RWR_HIP(hipMemcpy2DAsync(ids, (size_t)row_stride * sizeof(int64_t), g->d_out_id.p, (size_t)top_n * sizeof(int64_t),
-                             (size_t)top_n * sizeof(int64_t), (size_t)K, hipMemcpyDeviceToHost, s));
-    RWR_HIP(hipMemcpy2DAsync(scores, (size_t)row_stride * sizeof(double), g->d_out_score.p,
-                             (size_t)top_n * sizeof(double), (size_t)top_n * sizeof(double), (size_t)K,
-                             hipMemcpyDeviceToHost, s));
+    if (ids && scores) {   // (NULL: the caller consumes the lists on the device, e.g. rwr_recommend_eval)
+        RWR_HIP(hipMemcpy2DAsync(ids, (size_t)row_stride * sizeof(int64_t), g->d_out_id.p, (size_t)top_n * sizeof(int64_t),
+                                 (size_t)top_n * sizeof(int64_t), (size_t)K, hipMemcpyDeviceToHost, s));
+        RWR_HIP(hipMemcpy2DAsync(scores, (size_t)row_stride * sizeof(double), g->d_out_score.p,
+                                 (size_t)top_n * sizeof(double), (size_t)top_n * sizeof(double), (size_t)K,
+                                 hipMemcpyDeviceToHost, s));
+    }
     RWR_HIP(hipStreamSynchronize(s));
     RWR_HIP(hipStreamSynchronize(g->stream2));
     for (int32_t k = 0; k < K; ++k) counts[k] = hc[k];

@@ -373,6 +373,83 @@ int32_t rank_group_select(rwr_graph *g, int G, int tg, const int32_t *d_slot_k, 
     return RWR_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Evaluation of a ranked list against a test set -- TweetRecommender/Experiment.cs:121-128.
+// One block walks the list in rank order; hits are numbered with an ordered block-wide prefix
+// (wave ballots), each hit's addend (double)nHits / (i + 1) is stored at its hit number, and a
+// single thread finally adds the addends in rank order (the reference's summation order).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_eval_ranked(const int64_t *__restrict__ ranked, int32_t cnt,
+                                                      const int64_t *__restrict__ test_sorted, int32_t n_test,
+                                                      double *__restrict__ terms, int64_t *__restrict__ out_hits,
+                                                      double *__restrict__ out_sum)
+{
+    __shared__ int wave_cnt[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int32_t c0 = 0; c0 < cnt; c0 += 1024) {
+        const int32_t pos = c0 + tid;
+        bool hit = false;
+        if (pos < cnt) {
+            const int64_t id = ranked[pos];
+            int32_t lo = 0, hi = n_test;                    // testSet.Contains (Experiment.cs:124)
+            while (lo < hi) {
+                const int32_t mid = lo + (hi - lo) / 2;
+                const int64_t v = test_sorted[mid];
+                if (v < id) lo = mid + 1;
+                else hi = mid;
+            }
+            hit = lo < n_test && test_sorted[lo] == id;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wave_cnt[wv] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int q = 0; q < wv; ++q) off += wave_cnt[q];
+        if (hit) {
+            const int h = off + __popcll(m & ((1ull << lane) - 1ull)) + 1;    // nHits after this hit (:125)
+            if (h <= n_test) terms[h - 1] = (double)h / (double)(pos + 1);    // (double)nHits / (i + 1)  (:126)
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int q = 0; q < 16; ++q) tot += wave_cnt[q];
+            base_s += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int nh = base_s < n_test ? base_s : n_test;
+        double sum = 0.0;
+        for (int h = 0; h < nh; ++h) sum += terms[h];                          // sumPrecision += ... in rank order
+        *out_hits = base_s;
+        *out_sum = sum;
+    }
+}
+
+int32_t eval_ranked(rwr_graph *g, int32_t cnt, const int64_t *test_sorted_host, int64_t n_test, int64_t *n_hits,
+                    double *sum_precision)
+{
+    hipStream_t s = g->stream;
+    DevBuf<int64_t> d_test, d_hits;
+    DevBuf<double> d_terms, d_sum;
+    RWR_TRY(d_test.alloc((size_t)n_test));
+    RWR_TRY(d_terms.alloc((size_t)n_test));
+    RWR_TRY(d_hits.alloc(1));
+    RWR_TRY(d_sum.alloc(1));
+    if (n_test > 0)
+        RWR_HIP(hipMemcpyAsync(d_test.p, test_sorted_host, sizeof(int64_t) * (size_t)n_test, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_eval_ranked, dim3(1), dim3(1024), 0, s, g->d_out_id.p, cnt, d_test.p, (int32_t)n_test, d_terms.p,
+                       d_hits.p, d_sum.p);
+    RWR_HIP(hipGetLastError());
+    RWR_HIP(hipMemcpyAsync(n_hits, d_hits.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipMemcpyAsync(sum_precision, d_sum.p, sizeof(double), hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipStreamSynchronize(s));
+    return RWR_OK;
+}
+
 int rank_select_max_k() { return SEL_MAX_K; }
 
 }  // namespace rwr

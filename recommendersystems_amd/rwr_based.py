@@ -253,6 +253,19 @@ class Recommender:
         c = int(cnt.value)
         return list(zip(ids[:c].tolist(), sc[:c].tolist()))
 
+    def RecommendationEval(self, idxTargetUser: int, dampingFactor: float, nIteration: int, testSet):
+        """Recommendation + the harness's evaluation of it (Experiment.cs:109,121-128) without bringing the list
+        to the host: returns (nHits, sumPrecision, len(list)); MAP contribution = sumPrecision / nHits."""
+        g = self.graph
+        if g.edges is not None and idxTargetUser not in g.edges:
+            raise KeyError(idxTargetUser)
+        t = np.ascontiguousarray(sorted(testSet), dtype=np.int64)
+        hits, sp, ln = C.c_int64(0), C.c_double(0.0), C.c_int64(0)
+        _lib.check(_lib.load().rwr_recommend_eval(g._handle(), int(idxTargetUser), C.c_float(dampingFactor),
+                                                  int(nIteration), _p(t, C.c_int64), len(t), C.byref(hits),
+                                                  C.byref(sp), C.byref(ln)))
+        return int(hits.value), float(sp.value), int(ln.value)
+
     def RecommendationBatch(self, seeds, dampingFactor: float, nIteration: int, topN: int):
         """Batch entry (an addition, see include/rwr.h): (ids[K,topN], scores[K,topN], counts[K])."""
         lib = _lib.load()

@@ -306,3 +306,21 @@ def test_row_partitioned_logical_ranks(amd, world):
         pr = pt.PartitionedRecommender(g)
         i2, s2, c2 = pr.RecommendationBatch(seeds, 0.15, 10, 20)
         assert (i2 == oi).all() and (c2 == oc).all() and np.abs(s2 - os_).max() <= 1e-9
+
+
+def test_recommend_eval_bitwise(amd):
+    """Section 8(f)-1: Hits / running precision of Experiment.cs:121-128 computed on the device."""
+    from oracle.c_oracle import evaluate as c_eval
+    g = gg.random_graph(61, n_users=400, n_items=3000, n_likes=12000, n_friend=200, n_mention=100)
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g)
+    rng = np.random.default_rng(9)
+    item_ids = g["node_id"][g["node_type"] == gg.NODE_ITEM]
+    for seed in (0, 57, 399):
+        ids, _ = F.recommend(seed, 0.15, 8)
+        test = set(rng.choice(item_ids, 40, replace=False).tolist()) | {-5}
+        hits, sp, ln = amd.Recommender(G).RecommendationEval(seed, 0.15, 8, test)
+        oh, osp = c_eval(ids, sorted(test))
+        assert ln == len(ids) and hits == oh
+        assert np.float64(sp).view(np.uint64) == np.float64(osp).view(np.uint64)
+    assert amd.Recommender(G).RecommendationEval(0, 0.15, 3, set())[:2] == (0, 0.0)

@@ -137,3 +137,23 @@ def test_batch_matches_single():
         i1, s1 = F.recommend(s, 0.15, 6, 5)
         assert cnt[k] == len(i1)
         assert list(ids[k, :cnt[k]]) == list(i1) and (bits(sc[k, :cnt[k]]) == bits(s1)).all()
+
+
+def test_evaluate_literal_vs_c():
+    """Experiment.cs:121-128 restated twice (hits, running-precision sum over the full ranked list)."""
+    from oracle.c_oracle import evaluate as c_eval
+    g = gg.random_graph(**CASES[1])
+    G = py_graph(g)
+    rec = po.Recommender(G, dense_restart=False).Recommendation(0, 0.15, 10)
+    ids = [r[0] for r in rec]
+    rng = np.random.default_rng(5)
+    test = set(rng.choice(ids, 7, replace=False).tolist()) | {123456789}      # one id that is not in the list
+    h, sp = po.evaluate(rec, test)
+    hc, spc = c_eval(ids, sorted(test))
+    assert h == hc == 7 and struct.pack(">d", sp) == struct.pack(">d", spc)
+    # hand check: hits at 0-based ranks r1 < r2 < ... contribute 1/(r1+1) + 2/(r2+1) + ...
+    pos = sorted(ids.index(t) for t in test if t in ids)
+    acc = 0.0
+    for k, p in enumerate(pos):
+        acc += float(k + 1) / (p + 1)
+    assert acc == sp
