@@ -54,7 +54,8 @@ def main():
     ap.add_argument("--tile-seeds", type=int, default=0)
     ap.add_argument("--tile-group", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seeds", type=int, default=0, help="seeds in the CPU sample (0 = one per core)")
+    ap.add_argument("--cpu-seeds", type=int, default=0, help="seeds in the CPU sample (0 = one per thread)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,7 +172,8 @@ def cpu_baseline(flat, seeds, ids, sc, cnt, args):
     in oracle/rwr_oracle.c, timed on this host on a bounded sample of the same workload, and used
     to check the GPU result of that sample bitwise."""
     from oracle.c_oracle import FlatGraph, max_threads
-    cores = max_threads()
+    # the GPU box gives one GPU's job a share of 16 host cores (more threads only oversubscribe them)
+    cores = min(max_threads(), len(os.sched_getaffinity(0)), args.cpu_threads)
     ks = args.cpu_seeds or cores
     ks = min(ks, len(seeds))
     F = FlatGraph(**flat)

@@ -324,3 +324,15 @@ def test_recommend_eval_bitwise(amd):
         assert ln == len(ids) and hits == oh
         assert np.float64(sp).view(np.uint64) == np.float64(osp).view(np.uint64)
     assert amd.Recommender(G).RecommendationEval(0, 0.15, 3, set())[:2] == (0, 0.0)
+
+
+def test_cpp_host_mirror_runs_the_kats():
+    """include/recommenders/rwr_based.hpp + tests/cpp/experiment_like.cpp: the caller pattern of
+    Experiment.cs:104-128 in C++ against librwr (built by __graft_entry__.build())."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "experiment_like")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "experiment_like: ok" in out.stdout
