@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
                                                       const double *__restrict__ X, double *__restrict__ Y,
                                                       const int32_t *__restrict__ seeds, double c1,
                                                       int skip_seed_row, const uint32_t *__restrict__ nz_in,
-                                                      uint32_t *__restrict__ nz_out)
+                                                      uint32_t *__restrict__ nz_out,
+                                                      const uint32_t *__restrict__ act)
 {
     static_assert(G >= 8 && G <= 64, "chunked SpMM needs 8 <= G <= 64");
     constexpr int RPW = WAVE / G;
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
     const size_t nzw = ((size_t)n + 31) / 32;
     if (CHECK) nz_in += (size_t)tile * nzw;
     if (WRITE) nz_out += (size_t)tile * nzw;
+    if (CHECK && act) act += (size_t)tile * nzw;
     const int lane = threadIdx.x & (WAVE - 1);
     const int sub = lane / G, k = lane % G;
     const int gbase = (lane - k) << 2;      // byte address of the group's lane 0 for ds_bpermute
@@ -129,6 +131,8 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
             j = row_order[r];
             p = in_ptr[j];
             e = in_ptr[j + 1];
+            // first iterations: a row none of whose in-neighbours is non-zero (k_mark_active) stays exactly 0
+            if (CHECK && act && !((act[(uint32_t)j >> 5] >> (j & 31)) & 1u)) e = p;
         }
         double acc = 0.0;
         // the wave iterates while ANY group still has entries; finished groups idle (cnt = 0)
@@ -196,6 +200,30 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
             const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << (sub * G));
             if (k == 0 && j >= 0 && (nzb & gmask)) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
         }
+    }
+}
+
+// First iterations: destination rows that can become non-zero = out-neighbours (explicit links) of the rows of X
+// that hold a non-zero.  One thread per bitmap word of the tile; pushes over the RAW out-links.
+__global__ __launch_bounds__(256) void k_mark_active(int32_t n, const uint32_t *__restrict__ nz, uint32_t *__restrict__ act,
+                                                     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ dst,
+                                                     const uint8_t *__restrict__ etype)
+{
+    const size_t nzw = ((size_t)n + 31) / 32;
+    const int tile = blockIdx.y;
+    const size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= nzw) return;
+    uint32_t w = nz[(size_t)tile * nzw + wi];
+    uint32_t *a = act + (size_t)tile * nzw;
+    while (w) {
+        const int b = __builtin_ctz(w);
+        w &= w - 1;
+        const int64_t i = (int64_t)wi * 32 + b;
+        for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p)
+            if (etype[p] != RWR_EDGE_UNDEFINED) {
+                const int32_t t = dst[p];
+                atomicOr(&a[(uint32_t)t >> 5], 1u << (t & 31));
+            }
     }
 }
 
@@ -288,6 +316,67 @@ __global__ __launch_bounds__(256) void k_seed_terms(int32_t n, const int64_t *__
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < deg; q += (int64_t)gridDim.x * blockDim.x) {
         const double rw = c1 * x[(size_t)in_src[p0 + q] * G];
         out[q] = rw * in_w[p0 + q];
+    }
+}
+
+// EXACT mode while X is still sparse (iterations 0 and 1): all-zero rows add +0.0 to the seed row's chain, so the
+// chain only has to visit the non-zero rows of X -- in ascending node order, taking the links INTO the seed that
+// come from such a row first (Model.cs:85-93).  One wave per tile walks the tile's non-zero-row bitmap; lane = seed.
+template <int G>
+__global__ __launch_bounds__(64) void k_seed_chain_sparse(int32_t n, const int64_t *__restrict__ in_ptr,
+                                                          const int32_t *__restrict__ in_src,
+                                                          const uint8_t *__restrict__ dangling,
+                                                          const double *__restrict__ X, double *__restrict__ Y,
+                                                          const int32_t *__restrict__ seeds, double c1,
+                                                          const int64_t *__restrict__ evoff,
+                                                          const double *__restrict__ evterm,
+                                                          const uint32_t *__restrict__ nz_x, uint32_t *__restrict__ nz_out,
+                                                          unsigned int *__restrict__ gate)
+{
+    if (threadIdx.x == 0 && gate) __hip_atomic_fetch_add(gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const size_t nzw = ((size_t)n + 31) / 32;
+    const uint32_t *bits = nz_x + (size_t)tile * nzw;
+    const double *x = X + (size_t)tile * (size_t)n * G;
+    const bool consumer = lane < G;
+    const int k = lane % G;
+    int32_t s = -1;
+    int64_t p = 0, e = 0;
+    const double *termp = evterm;
+    if (consumer) {
+        s = seeds[tile * G + k];
+        if (s >= 0) {
+            p = in_ptr[s];
+            e = in_ptr[s + 1];
+            termp = evterm + evoff[tile * G + k] - p;
+        }
+    }
+    double acc = 0.0;
+    for (size_t w0 = 0; w0 < nzw; w0 += WAVE) {
+        const uint32_t word = (w0 + lane < nzw) ? bits[w0 + lane] : 0u;
+        unsigned long long mask = __ballot(word != 0u);
+        while (mask) {
+            const int l = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            uint32_t wv = (uint32_t)__builtin_amdgcn_readlane((int)word, l);
+            while (wv) {
+                const int b = __builtin_ctz(wv);
+                wv &= wv - 1;
+                const int32_t i = (int32_t)((w0 + l) * 32 + b);
+                if (consumer && s >= 0) {
+                    while (p < e && in_src[p] < i) ++p;                 // links from all-zero rows: addend +0.0
+                    while (p < e && in_src[p] == i) { acc += termp[p]; ++p; }   // links i -> seed first (Model.cs:85-88)
+                    const double xi = x[(size_t)i * G + k];
+                    const double rw = c1 * xi;
+                    acc += dangling[i] ? xi : (xi - rw);                // then the restart addend (Model.cs:91-93,96-97)
+                }
+            }
+        }
+    }
+    if (consumer && s >= 0) {
+        Y[(size_t)tile * (size_t)n * G + (size_t)s * G + k] = acc;
+        if (nz_out && acc != 0.0)
+            atomicOr(&nz_out[(size_t)tile * nzw + ((uint32_t)s >> 5)], 1u << (s & 31));
     }
 }
 
@@ -515,7 +604,8 @@ __global__ void k_exclude(int32_t n, int ntiles, int G, const int64_t *__restric
 
 template <int G>
 static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
-                        int skip, const uint32_t *nz_in, uint32_t *nz_out, hipStream_t s)
+                        int skip, const uint32_t *nz_in, uint32_t *nz_out, hipStream_t s,
+                        const uint32_t *act = nullptr)
 {
     constexpr int RPW = WAVE / G;
     unsigned want = cdiv((size_t)g->n, (size_t)RPW * 4);
@@ -527,7 +617,7 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
             static const size_t occ_lds = [] { const char *e = getenv("RWR_SPMM_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
 #define RWR_SPMM_LAUNCH2(CH, CHK, WR)                                                                              \
     hipLaunchKernelGGL((k_spmm_chunked<G, CH, CHK, WR>), dim3(gx, tg), dim3(256), occ_lds, s, g->n, g->in_ptr.p,   \
-                       g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, nz_in, nz_out)
+                       g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, nz_in, nz_out, act)
 #define RWR_SPMM_LAUNCH(CH)                                  \
     {                                                        \
         if (nz_in && nz_out) RWR_SPMM_LAUNCH2(CH, true, true);   \
@@ -559,8 +649,14 @@ static void launch_seed_terms(rwr_graph *g, int tg, const double *X, const int32
 }
 template <int G>
 static void launch_chain(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
-                         const int64_t *evoff, uint32_t *nz_out, unsigned int *gate, hipStream_t s)
+                         const int64_t *evoff, uint32_t *nz_out, unsigned int *gate, hipStream_t s,
+                         const uint32_t *nz_sparse = nullptr)
 {
+    if (nz_sparse) {   // X still sparse: visit only its non-zero rows
+        hipLaunchKernelGGL(k_seed_chain_sparse<G>, dim3(tg), dim3(64), 0, s, g->n, g->in_ptr.p, g->in_src.p,
+                           g->dangling.p, X, Y, seeds, c1, evoff, g->d_evterm.p, nz_sparse, nz_out, gate);
+        return;
+    }
     static const int variant = [] { const char *e = getenv("RWR_CHAIN"); return e ? atoi(e) : 1; }();   // 0 = simple reference kernel
     static const int dbg = [] { const char *e = getenv("RWR_CHAIN_DBG"); return e ? atoi(e) : 0; }();
     if (variant != 0) {
@@ -694,6 +790,14 @@ struct GroupIter {
         const uint32_t *nz_in = (it < nz_iters) ? nz_cur : nullptr;
         uint32_t *nz_out = (it + 1 < nz_iters) ? nz_oth : nullptr;
         if (nz_out) RWR_HIP(hipMemsetAsync(nz_out, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
+        // iterations 0 and 1: the non-zero rows are few enough to mark their out-neighbours; every other row is 0
+        static const int act_iters = [] { const char *e = getenv("RWR_ACT_ITERS"); return e ? atoi(e) : 2; }();
+        uint32_t *act = (nz_in && it < act_iters) ? g->d_nz.p + 2 * (size_t)tg * nzw : nullptr;
+        if (act) {
+            RWR_HIP(hipMemsetAsync(act, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(k_mark_active, dim3(cdiv(nzw, 256), tg), dim3(256), 0, s, n, nz_in, act, g->rowptr.p,
+                               g->dst.p, g->etype.p);
+        }
         if (exact && serial) s2 = s;
         if (exact) {
             // fork: the seed-row chain runs beside the SpMM on the second stream
@@ -704,7 +808,7 @@ struct GroupIter {
             if (s2 != s) RWR_HIP(hipStreamWaitEvent(s2, g->ev_fork, 0));
             hipEvent_t c0 = nullptr, c1e = nullptr;
             if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, s2)); }
-            RWR_DISPATCH_G(G, launch_chain<GG>(g, tg, X, Y, d_seeds, c1, d_evoff, nz_out, gate_it, s2));
+            RWR_DISPATCH_G(G, launch_chain<GG>(g, tg, X, Y, d_seeds, c1, d_evoff, nz_out, gate_it, s2, act ? nz_in : nullptr));
             if (prof) { RWR_HIP(hipEventRecord(c1e, s2)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
             RWR_HIP(hipEventRecord(g->ev_join, s2));
         } else {
@@ -719,7 +823,7 @@ struct GroupIter {
         }
         hipEvent_t a = nullptr, b = nullptr;
         if (prof) { a = pool.get(); b = pool.get(); RWR_HIP(hipEventRecord(a, s)); }
-        RWR_DISPATCH_G(G, launch_spmm<GG>(g, tg, X, Y, d_seeds, c1, exact ? 1 : 0, nz_in, nz_out, s));
+        RWR_DISPATCH_G(G, launch_spmm<GG>(g, tg, X, Y, d_seeds, c1, exact ? 1 : 0, nz_in, nz_out, s, act));
         if (prof) { RWR_HIP(hipEventRecord(b, s)); spmm_ev.push_back(a); spmm_ev.push_back(b); }
         if (exact) {
             if (s2 != s) RWR_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
@@ -768,7 +872,7 @@ static int32_t ensure_workspace(rwr_graph *g, int G, int32_t K, int *TG_out)
     RWR_TRY(g->Y.ensure((size_t)TG * n * G));
     RWR_TRY(g->d_seeds.ensure((size_t)ntiles * G));
     RWR_TRY(g->d_part.ensure((size_t)TG * RP_GRID * G));
-    RWR_TRY(g->d_nz.ensure(2 * (size_t)TG * ((n + 31) / 32)));
+    RWR_TRY(g->d_nz.ensure(3 * (size_t)TG * ((n + 31) / 32)));   // X, Y non-zero rows + active destination rows
     RWR_TRY(g->d_gate.ensure(64));
     *TG_out = TG;
     return RWR_OK;

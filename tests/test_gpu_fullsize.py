@@ -1,0 +1,99 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (config C2: 100 K users x 500 K items,
+10 M likes, nnz 20 M; config C4 -- the 100 M-like graph -- when RWR_TEST_C4=1), plus an oracle spot check on a few
+seeds.  The oracle cannot sweep these sizes in seconds, the properties can."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.c_oracle import FlatGraph
+
+pytestmark = pytest.mark.gpu
+
+CONFIG = "C4" if os.environ.get("RWR_TEST_C4") == "1" else "C2"
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def big():
+    import recommendersystems_amd as amd
+    from recommendersystems_amd import synth
+    g = synth.config(CONFIG)
+    flat = {k: g[k] for k in ("node_id", "node_type", "rowptr", "dst", "etype", "w")}
+    G = amd.Graph.from_flat(**flat)
+    G.buildGraph()
+    return amd, synth, g, flat, G
+
+
+def test_full_size_properties(big):
+    amd, synth, g, flat, G = big
+    U, I = g["users"], g["items"]
+    n = U + I
+    rec = amd.Recommender(G)
+    K = 96                                                    # 6 tiles of 16 (or 3 of 32), heavy and light seeds
+    seeds = synth.seeds_for(U, K, 0, K)
+    ids, sc, cnt = rec.RecommendationBatch(seeds, 0.15, 10, 100)
+    # (1) determinism: a second run is bitwise identical
+    ids2, sc2, cnt2 = rec.RecommendationBatch(seeds, 0.15, 10, 100)
+    assert (ids == ids2).all() and (bits(sc) == bits(sc2)).all() and (cnt == cnt2).all()
+    assert (cnt == 100).all()
+    rp, dst = flat["rowptr"], flat["dst"]
+    for k in range(K):
+        # (2) order: score descending, then id descending (Recommender.cs:35-38)
+        key = list(zip((-sc[k]).tolist(), (-ids[k]).tolist()))
+        assert key == sorted(key)
+        # (3) candidates are ITEM nodes the seed has not LIKEd (Recommender.cs:20-31); ids == node index here
+        assert (ids[k] >= U).all() and (ids[k] < n).all()
+        liked = set(dst[rp[seeds[k]]:rp[seeds[k] + 1]].tolist())
+        assert not (liked & set(ids[k].tolist()))
+        assert (sc[k] >= 0).all()
+    # (4) a batch row equals the single-seed call, and the top-N overload is a prefix of the full list
+    for k in (0, 37, K - 1):
+        single = rec.Recommendation(int(seeds[k]), 0.15, 10, 100)
+        assert [r[0] for r in single] == ids[k].tolist() and (bits([r[1] for r in single]) == bits(sc[k])).all()
+    full = rec.Recommendation(int(seeds[5]), 0.15, 10)
+    assert len(full) == I - len(set(dst[rp[seeds[5]]:rp[seeds[5] + 1]].tolist()))
+    assert [r[0] for r in full[:100]] == ids[5].tolist()
+    fk = [(-r[1], -r[0]) for r in full]
+    assert fk == sorted(fk)
+    # (5) rank mass n is conserved and ranks are non-negative
+    m = amd.Model(G, float(np.float32(0.15)), int(seeds[3]))
+    m.run(10)
+    assert abs(m.rank.sum() - n) < 1e-7 * n and (m.rank >= 0).all()
+    # (6) oracle spot check, bitwise (EXACT mode is the default)
+    F = FlatGraph(**flat)
+    spot = seeds[[0, K // 2]]
+    oi, os_, oc = F.recommend_batch(spot, 0.15, 10, 100, n_threads=2)
+    assert (oi == ids[[0, K // 2]]).all() and (bits(os_) == bits(sc[[0, K // 2]])).all()
+    r, _ = F.model_run(float(np.float32(0.15)), int(seeds[3]), 0, 10)
+    assert (bits(r) == bits(m.rank)).all()
+
+
+def test_full_size_fast_mode_within_tolerance(big):
+    amd, synth, g, flat, G = big
+    Gf = amd.Graph.from_flat(**flat, mode="fast")
+    Gf.buildGraph()
+    seeds = synth.seeds_for(g["users"], 64, 0, 64)
+    ids, sc, cnt = amd.Recommender(G).RecommendationBatch(seeds, 0.15, 10, 100)
+    idf, scf, cntf = amd.Recommender(Gf).RecommendationBatch(seeds, 0.15, 10, 100)
+    assert (ids == idf).all() and (cnt == cntf).all()           # top-k lists identical
+    assert np.abs(sc - scf).max() <= 1e-6                       # north_star: rank scores within 1e-6
+    Gf.close()
+
+
+def test_monotone_id_relabelling_keeps_scores(big):
+    """Ids only break ties (Recommender.cs:36-37): an order-preserving relabelling of the ids leaves every score and
+    every position unchanged."""
+    amd, synth, g, flat, G = big
+    flat2 = dict(flat)
+    flat2["node_id"] = flat["node_id"] * 3 + 7
+    G2 = amd.Graph.from_flat(**flat2)
+    G2.buildGraph()
+    seeds = synth.seeds_for(g["users"], 32, 0, 32)
+    ids, sc, _ = amd.Recommender(G).RecommendationBatch(seeds, 0.15, 10, 50)
+    ids2, sc2, _ = amd.Recommender(G2).RecommendationBatch(seeds, 0.15, 10, 50)
+    assert (ids2 == ids * 3 + 7).all() and (bits(sc) == bits(sc2)).all()
+    G2.close()
