@@ -209,9 +209,11 @@ __global__ __launch_bounds__(256) void k_mark_active(int32_t n, const uint32_t *
                                                      const int64_t *__restrict__ rowptr, const int32_t *__restrict__ dst,
                                                      const uint8_t *__restrict__ etype)
 {
+    // one WAVE per bitmap word; the lanes stride over the out-links of each non-zero row of that word
     const size_t nzw = ((size_t)n + 31) / 32;
     const int tile = blockIdx.y;
-    const size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const size_t wi = (size_t)blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
     if (wi >= nzw) return;
     uint32_t w = nz[(size_t)tile * nzw + wi];
     uint32_t *a = act + (size_t)tile * nzw;
@@ -219,7 +221,8 @@ __global__ __launch_bounds__(256) void k_mark_active(int32_t n, const uint32_t *
         const int b = __builtin_ctz(w);
         w &= w - 1;
         const int64_t i = (int64_t)wi * 32 + b;
-        for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p)
+        const int64_t p1 = rowptr[i + 1];
+        for (int64_t p = rowptr[i] + lane; p < p1; p += WAVE)
             if (etype[p] != RWR_EDGE_UNDEFINED) {
                 const int32_t t = dst[p];
                 atomicOr(&a[(uint32_t)t >> 5], 1u << (t & 31));
@@ -791,11 +794,14 @@ struct GroupIter {
         uint32_t *nz_out = (it + 1 < nz_iters) ? nz_oth : nullptr;
         if (nz_out) RWR_HIP(hipMemsetAsync(nz_out, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
         // iterations 0 and 1: the non-zero rows are few enough to mark their out-neighbours; every other row is 0
-        static const int act_iters = [] { const char *e = getenv("RWR_ACT_ITERS"); return e ? atoi(e) : 2; }();
+        // (iteration 1 only on sparse graphs: on dense ones -- hundreds of links per node -- marking the 2-hop
+        //  neighbourhood costs more atomics than the skipped rows save)
+        static const int act_env = [] { const char *e = getenv("RWR_ACT_ITERS"); return e ? atoi(e) : -1; }();
+        const int act_iters = act_env >= 0 ? act_env : ((g->nnz / (g->n > 0 ? g->n : 1)) <= 64 ? 2 : 1);
         uint32_t *act = (nz_in && it < act_iters) ? g->d_nz.p + 2 * (size_t)tg * nzw : nullptr;
         if (act) {
             RWR_HIP(hipMemsetAsync(act, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
-            hipLaunchKernelGGL(k_mark_active, dim3(cdiv(nzw, 256), tg), dim3(256), 0, s, n, nz_in, act, g->rowptr.p,
+            hipLaunchKernelGGL(k_mark_active, dim3(cdiv(nzw, 4), tg), dim3(256), 0, s, n, nz_in, act, g->rowptr.p,
                                g->dst.p, g->etype.p);
         }
         if (exact && serial) s2 = s;
@@ -868,6 +874,8 @@ static int32_t ensure_workspace(rwr_graph *g, int G, int32_t K, int *TG_out)
     if (TG < 1) TG = 1;
     if (TG > ntiles) TG = ntiles;
     if (TG > 65535 / G) TG = 65535 / G;   // grid.y of the per-slot kernels is TG * G
+    // exact mode: every tile's chain workgroup must be resident beside the SpMM (one per CU, see k_gate)
+    if (g->opts.mode != RWR_MODE_FAST && g->opts.tile_group <= 0 && TG > 192) TG = 192;
     RWR_TRY(g->X.ensure((size_t)TG * n * G));
     RWR_TRY(g->Y.ensure((size_t)TG * n * G));
     RWR_TRY(g->d_seeds.ensure((size_t)ntiles * G));
