@@ -336,3 +336,58 @@ def test_cpp_host_mirror_runs_the_kats():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "experiment_like: ok" in out.stdout
+
+
+def test_concurrent_host_threads_independent_handles(amd):
+    """The reference runs up to 10 worker threads, each with its own Graph/Recommender (Program.cs:11,61-66;
+    Experiment.cs:71,104,108): handles must be usable concurrently from distinct host threads."""
+    import threading
+    cases = [dict(seed=80 + t, n_users=200 + 30 * t, n_items=900, n_likes=5000, n_friend=100, n_mention=60) for t in range(6)]
+    graphs = [gg.random_graph(**c) for c in cases]
+    expect = []
+    for g in graphs:
+        F = FlatGraph(**g)
+        expect.append([F.recommend(s, 0.15, 10) for s in (0, 11, 57)])
+    results = [None] * len(graphs)
+    errors = []
+
+    def worker(t):
+        try:
+            G = dev_graph(amd, graphs[t])
+            rec = amd.Recommender(G)
+            out = []
+            for _ in range(3):                                   # repeat to overlap with the other threads
+                out = [rec.Recommendation(s, 0.15, 10) for s in (0, 11, 57)]
+            results[t] = out
+            G.close()
+        except Exception as e:                                   # pragma: no cover
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(len(graphs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(300)
+    assert not errors, errors
+    for t in range(len(graphs)):
+        for got, (ids, sc) in zip(results[t], expect[t]):
+            assert [r[0] for r in got] == ids.tolist()
+            assert (bits([r[1] for r in got]) == bits(sc)).all()
+
+
+def test_degenerate_graphs(amd):
+    # a single user, no links, no items
+    g = gg._from_lists(np.array([5], dtype=np.int64), np.array([gg.NODE_USER], dtype=np.uint8), {0: []})
+    G = dev_graph(amd, g)
+    assert amd.Recommender(G).Recommendation(0, 0.15, 4) == []
+    m = amd.Model(G, 0.15, 0)
+    m.run(3)
+    assert m.rank.tolist() == [1.0]                              # dangling seed: all mass returns to it
+    # items only reachable by nobody: every candidate has score 0, ordered by id descending
+    node_id = np.array([1, 40, 20, 30], dtype=np.int64)
+    node_type = np.array([gg.NODE_USER, gg.NODE_ITEM, gg.NODE_ITEM, gg.NODE_ITEM], dtype=np.uint8)
+    g = gg._from_lists(node_id, node_type, {0: [], 1: [], 2: [], 3: []})
+    G = dev_graph(amd, g)
+    assert amd.Recommender(G).Recommendation(0, 0.15, 5) == [(40, 0.0), (30, 0.0), (20, 0.0)]
+    ids, sc, cnt = amd.Recommender(G).RecommendationBatch(np.array([0, 0], dtype=np.int32), 0.15, 5, 2)
+    assert ids.tolist() == [[40, 30], [40, 30]] and cnt.tolist() == [2, 2]
