@@ -93,6 +93,7 @@ def main():
     G.buildGraph()
     rec = Recommender(G)
     t_create = time.time() - t0
+    torch.cuda.empty_cache()          # the generator's sort scratch: give it back before the library sizes its workspace
     seeds = synth.seeds_for(U, K * world, rank * K, K)
     log(rank, f"graph resident on GPU in {t_create:.1f}s (device build {G.stats()['build_ms']:.0f} ms); "
               f"{K} seeds per GPU, T={T_ITER}, top_n={TOP_N}, mode={args.mode}")
@@ -159,7 +160,7 @@ def main():
                                    "call_wall": st["total_wall_ms"] / args.steps},
             "graph_build_ms": st["build_ms"], "graph_create_s": t_create,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(flat, seeds, ids, sc, cnt, args)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -10,6 +10,9 @@ struct rwr_graph {
     int32_t n_items = 0;     // nodes of type ITEM
     int32_t uniform = 0;     // every row's explicit raw weights equal
     int32_t max_in_deg = 0;
+    // rows of row_order (in-degree descending) with in-degree >= 128 / >= 32 / >= 4: lane-width bins of the K = 1 vector SpMV
+    int32_t bin_end[3] = {0, 0, 0};
+    int32_t bin_huge = 0;    // rows with in-degree >= 2048: one 1024-thread workgroup per row
     rwr_opts opts{};
 
     // node SoA (struct Node, Graph.cs:4-17)

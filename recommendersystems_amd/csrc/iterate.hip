@@ -81,6 +81,91 @@ __global__ __launch_bounds__(256) void k_spmm(int32_t n, const int64_t *__restri
     }
 }
 
+// K = 1, FAST mode: the classic vector-CSR SpMV.  W lanes share one destination row: each lane streams every W-th
+// entry of the row's in-list (coalesced index and weight reads), gathers x, keeps a private partial sum, and the W
+// partials are combined with a shuffle butterfly whose shape depends only on W -- rows of equal structure get
+// bit-identical results, so structural ties stay tied.  The summation order differs from the reference's, which is
+// why this kernel exists only in FAST mode (scores within 1e-6).  Rows are binned by in-degree (row_order is sorted
+// by it): W = 64 / 16 / 4 / 1.
+template <int W>
+__global__ __launch_bounds__(256) void k_spmv_vector(int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
+                                                     const int32_t *__restrict__ in_src,
+                                                     const double *__restrict__ in_w,
+                                                     const int32_t *__restrict__ row_order,
+                                                     const double *__restrict__ x, double *__restrict__ y, double c1)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = (int)(gid % W);
+    for (int64_t r = r0 + gid / W; r < r1; r += ((int64_t)gridDim.x * blockDim.x) / W) {
+        const int32_t j = row_order[r];
+        const int64_t p0 = in_ptr[j], p1 = in_ptr[j + 1];
+        double acc = 0.0;
+        int64_t p = p0 + l;
+        for (; p + 3 * W < p1; p += 4 * W) {               // four independent gathers in flight per lane
+            const double a0 = c1 * x[in_src[p]], a1 = c1 * x[in_src[p + W]];
+            const double a2 = c1 * x[in_src[p + 2 * W]], a3 = c1 * x[in_src[p + 3 * W]];
+            acc += a0 * in_w[p];
+            acc += a1 * in_w[p + W];
+            acc += a2 * in_w[p + 2 * W];
+            acc += a3 * in_w[p + 3 * W];
+        }
+        for (; p < p1; p += W) acc += (c1 * x[in_src[p]]) * in_w[p];
+#pragma unroll
+        for (int off = W / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, W);
+        if (l == 0) y[j] = acc;
+    }
+}
+
+// very long rows (in-degree >= 2048): a whole 1024-thread workgroup per row; per-lane partials, shuffle butterfly per
+// wave, then the 16 wave sums are staged in LDS and added in wave order
+__global__ __launch_bounds__(1024) void k_spmv_row_block(int32_t r1, const int64_t *__restrict__ in_ptr,
+                                                         const int32_t *__restrict__ in_src,
+                                                         const double *__restrict__ in_w,
+                                                         const int32_t *__restrict__ row_order,
+                                                         const double *__restrict__ x, double *__restrict__ y, double c1)
+{
+    __shared__ double wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int32_t r = blockIdx.x; r < r1; r += gridDim.x) {
+        const int32_t j = row_order[r];
+        const int64_t p0 = in_ptr[j], p1 = in_ptr[j + 1];
+        double acc = 0.0;
+        int64_t p = p0 + tid;
+        for (; p + 3 * 1024 < p1; p += 4 * 1024) {
+            const double a0 = c1 * x[in_src[p]], a1 = c1 * x[in_src[p + 1024]];
+            const double a2 = c1 * x[in_src[p + 2048]], a3 = c1 * x[in_src[p + 3072]];
+            acc += a0 * in_w[p];
+            acc += a1 * in_w[p + 1024];
+            acc += a2 * in_w[p + 2048];
+            acc += a3 * in_w[p + 3072];
+        }
+        for (; p < p1; p += 1024) acc += (c1 * x[in_src[p]]) * in_w[p];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) wsum[wv] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int q = 0; q < 16; ++q) t += wsum[q];
+            y[j] = t;
+        }
+        __syncthreads();
+    }
+}
+
+static void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hipStream_t s)
+{
+    const int32_t n = g->n, bh = g->bin_huge, b0 = g->bin_end[0], b1 = g->bin_end[1], b2 = g->bin_end[2];
+    if (bh > 0)
+        hipLaunchKernelGGL(k_spmv_row_block, dim3(bh < 4096 ? bh : 4096), dim3(1024), 0, s, bh, g->in_ptr.p, g->in_src.p,
+                           g->in_w.p, g->row_order.p, x, y, c1);
+    auto grid = [](int64_t rows, int W) { int64_t blocks = (rows * W + 255) / 256; return (unsigned)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks)); };
+    if (b0 > bh) hipLaunchKernelGGL(k_spmv_vector<64>, dim3(grid(b0 - bh, 64)), dim3(256), 0, s, bh, b0, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, x, y, c1);
+    if (b1 > b0) hipLaunchKernelGGL(k_spmv_vector<16>, dim3(grid(b1 - b0, 16)), dim3(256), 0, s, b0, b1, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, x, y, c1);
+    if (b2 > b1) hipLaunchKernelGGL(k_spmv_vector<4>, dim3(grid(b2 - b1, 4)), dim3(256), 0, s, b1, b2, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, x, y, c1);
+    if (n > b2) hipLaunchKernelGGL(k_spmv_vector<1>, dim3(grid(n - b2, 1)), dim3(256), 0, s, b2, n, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, x, y, c1);
+}
+
 // Chunked variant for G >= 8: a lane group fetches G consecutive in-neighbour indices (and
 // weights) of its row with ONE coalesced load -- lane k takes entry p+k -- and hands entry t
 // to the whole group through the LDS crossbar (ds_bpermute), instead of G lanes loading the
@@ -558,22 +643,27 @@ __global__ __launch_bounds__(RP_BLOCK) void k_restart_partial(int32_t n, const u
 }
 
 template <int G>
-__global__ void k_restart_final(int32_t n, int ntiles, int nblk, const double *__restrict__ part,
-                                double *__restrict__ Y, const int32_t *__restrict__ seeds,
-                                uint32_t *__restrict__ nz_out)
+__global__ __launch_bounds__(64) void k_restart_final(int32_t n, int ntiles, int nblk, const double *__restrict__ part,
+                                                      double *__restrict__ Y, const int32_t *__restrict__ seeds,
+                                                      uint32_t *__restrict__ nz_out)
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per (tile, seed): lanes sum a strided share of the per-block partials, then a fixed butterfly
+    const int q = blockIdx.x;
     if (q >= ntiles * G) return;
-    const int tile = q / G, k = q % G;
+    const int tile = q / G, k = q % G, lane = threadIdx.x;
     const int32_t s = seeds[q];
     if (s < 0) return;
     double R = 0.0;
-    for (int b = 0; b < nblk; ++b) R += part[((size_t)tile * nblk + b) * G + k];
-    double *y = Y + (size_t)tile * (size_t)n * G + (size_t)s * G + k;
-    const double v = *y + R;
-    *y = v;
-    if (nz_out && v != 0.0)
-        atomicOr(&nz_out[(size_t)tile * (((size_t)n + 31) / 32) + ((uint32_t)s >> 5)], 1u << (s & 31));
+    for (int b = lane; b < nblk; b += WAVE) R += part[((size_t)tile * nblk + b) * G + k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) R += __shfl_xor(R, off, WAVE);
+    if (lane == 0) {
+        double *y = Y + (size_t)tile * (size_t)n * G + (size_t)s * G + k;
+        const double v = *y + R;
+        *y = v;
+        if (nz_out && v != 0.0)
+            atomicOr(&nz_out[(size_t)tile * (((size_t)n + 31) / 32) + ((uint32_t)s >> 5)], 1u << (s & 31));
+    }
 }
 
 // Model ctor, Model.cs:42-49: rank[seed] = nNodes, everything else 0
@@ -614,6 +704,13 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
     unsigned want = cdiv((size_t)g->n, (size_t)RPW * 4);
     unsigned gx = want < 8192u ? want : 8192u;
     static const int variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
+    if constexpr (G == 1) {
+        // single seed, FAST mode: vector-CSR SpMV (re-associated sums are allowed there); EXACT keeps lane = row
+        if (g->opts.mode == RWR_MODE_FAST && tg == 1 && !skip && variant != 0) {
+            launch_spmv_vector(g, X, Y, c1, s);
+            return;
+        }
+    }
     if constexpr (G >= 8) {
         if (variant != 0) {
             // experiment knob: dynamic LDS per block that caps the blocks per CU (0 = no cap)
@@ -689,7 +786,7 @@ template <int G>
 static void launch_restart_final(rwr_graph *g, int tg, double *Y, const int32_t *seeds, uint32_t *nz_out,
                                  hipStream_t s)
 {
-    hipLaunchKernelGGL(k_restart_final<G>, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, g->n, tg, RP_GRID,
+    hipLaunchKernelGGL(k_restart_final<G>, dim3((unsigned)tg * G), dim3(64), 0, s, g->n, tg, RP_GRID,
                        g->d_part.p, Y, seeds, nz_out);
 }
 

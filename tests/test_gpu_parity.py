@@ -391,3 +391,24 @@ def test_degenerate_graphs(amd):
     assert amd.Recommender(G).Recommendation(0, 0.15, 5) == [(40, 0.0), (30, 0.0), (20, 0.0)]
     ids, sc, cnt = amd.Recommender(G).RecommendationBatch(np.array([0, 0], dtype=np.int32), 0.15, 5, 2)
     assert ids.tolist() == [[40, 30], [40, 30]] and cnt.tolist() == [2, 2]
+
+
+@pytest.mark.parametrize("case", SMALL[:2] + MEDIUM, ids=lambda c: f"g{c['seed']}")
+def test_single_seed_fast_mode_vector_spmv(amd, case):
+    """K = 1 in FAST mode runs the vector-CSR SpMV (lanes share a row, shuffle reduction): scores within 1e-6,
+    ranked ids identical, structural ties intact."""
+    g = gg.random_graph(**case)
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g, mode="fast")
+    rec = amd.Recommender(G)
+    for seed in (0, case["n_users"] // 2, case["n_users"] - 1):
+        ids, sc = F.recommend(seed, 0.15, 10)
+        got = rec.Recommendation(seed, 0.15, 10)
+        assert len(got) == len(ids)
+        assert np.abs(np.array([r[1] for r in got]) - sc).max() <= 1e-6
+        # positions may only differ inside groups of (near-)equal scores; the top of the list must match exactly
+        assert [r[0] for r in got[:10]] == ids[:10].tolist()
+        m = amd.Model(G, po.widen_float(0.15), seed)
+        m.run(10)
+        r, _ = F.model_run(po.widen_float(0.15), seed, 0, 10)
+        assert np.abs(m.rank - r).max() <= 1e-6 and abs(m.rank.sum() - F.n) < 1e-9 * F.n
