@@ -1,0 +1,280 @@
+"""Config-1 plumbing (BASELINE.json configs[0]): the reference's host flow
+    SQLite ego network -> DataLoader.graphConfiguration -> (relabel) -> Graph/buildGraph -> Recommendation -> Hits / MAP
+restated as TEST INFRASTRUCTURE so that the whole `Program -> result.dat` path can be replayed without .NET, once over the
+CPU oracle's classes and once over the GPU mirror classes -- the caller code below is the SAME for both, which is the
+point of the drop-in boundary.
+
+Follows TweetRecommender/DataLoader.cs (:38-77 nodes/links, :122-140 fold split, :142-254 methodologies,
+:256-436 features), SQLiteAdapter.cs (:27-125 queries) and Experiment.cs (:69-138 fold loop, relabel, evaluation).
+Enumeration orders of HashSet/Dictionary are taken as insertion order and SQL row order as rowid order; the reference
+leaves both unspecified (no ORDER BY), and parity is only ever asserted at the Graph boundary.
+"""
+from __future__ import annotations
+
+import math
+import sqlite3
+
+(BASELINE, INCL_FRIENDSHIP, INCL_FOLLOWSHIP_ON_THIRDPARTY, INCL_AUTHORSHIP, INCL_MENTIONCOUNT, INCL_ALLFOLLOWSHIP,
+ INCL_FRIENDSHIP_AUTHORSHIP, INCL_FRIENDSHIP_MENTIONCOUNT, ALL, EXCL_FRIENDSHIP, EXCL_FOLLOWSHIP_ON_THIRDPARTY,
+ EXCL_AUTHORSHIP, EXCL_MENTIONCOUNT, INCL_FOLLOWSHIP_ON_THIRDPARTY_AND_AUTHORSHIP,
+ INCL_FOLLOWSHIP_ON_THIRDPARTY_AND_MENTIONCOUNT, INCL_AUTHORSHIP_AND_MENTIONCOUNT) = range(16)     # Experiment.cs:7-15
+FRIENDSHIP, FOLLOWSHIP_ON_THIRDPARTY, AUTHORSHIP, MENTIONCOUNT = range(4)                              # Experiment.cs:16
+
+FEATURES = {                                                                                          # DataLoader.cs:144-212
+    BASELINE: [], INCL_FRIENDSHIP: [FRIENDSHIP], INCL_FOLLOWSHIP_ON_THIRDPARTY: [FOLLOWSHIP_ON_THIRDPARTY],
+    INCL_AUTHORSHIP: [AUTHORSHIP], INCL_MENTIONCOUNT: [FRIENDSHIP, MENTIONCOUNT],
+    INCL_ALLFOLLOWSHIP: [FRIENDSHIP, FOLLOWSHIP_ON_THIRDPARTY], INCL_FRIENDSHIP_AUTHORSHIP: [FRIENDSHIP, AUTHORSHIP],
+    INCL_FRIENDSHIP_MENTIONCOUNT: [FRIENDSHIP, MENTIONCOUNT],
+    ALL: [FRIENDSHIP, FOLLOWSHIP_ON_THIRDPARTY, AUTHORSHIP, MENTIONCOUNT],
+    EXCL_FRIENDSHIP: [FRIENDSHIP, FOLLOWSHIP_ON_THIRDPARTY, AUTHORSHIP, MENTIONCOUNT],
+    EXCL_FOLLOWSHIP_ON_THIRDPARTY: [FRIENDSHIP, AUTHORSHIP, MENTIONCOUNT],
+    EXCL_AUTHORSHIP: [FRIENDSHIP, FOLLOWSHIP_ON_THIRDPARTY, MENTIONCOUNT],
+    EXCL_MENTIONCOUNT: [FRIENDSHIP, FOLLOWSHIP_ON_THIRDPARTY, AUTHORSHIP],
+    INCL_FOLLOWSHIP_ON_THIRDPARTY_AND_AUTHORSHIP: [FOLLOWSHIP_ON_THIRDPARTY, AUTHORSHIP],
+    INCL_FOLLOWSHIP_ON_THIRDPARTY_AND_MENTIONCOUNT: [FRIENDSHIP, FOLLOWSHIP_ON_THIRDPARTY, MENTIONCOUNT],
+    INCL_AUTHORSHIP_AND_MENTIONCOUNT: [AUTHORSHIP, MENTIONCOUNT],
+}
+
+
+class Api:
+    """The few names the harness needs from an implementation of Recommenders.RWRBased."""
+
+    def __init__(self, Node, ForwardLink, Graph, Recommender, USER, ITEM, ETC, UNDEFINED, LIKE, FRIENDSHIP_E, FOLLOW,
+                 MENTION, AUTHORSHIP_E):
+        self.Node, self.ForwardLink, self.Graph, self.Recommender = Node, ForwardLink, Graph, Recommender
+        self.USER, self.ITEM, self.ETC = USER, ITEM, ETC
+        self.UNDEFINED, self.LIKE, self.FRIENDSHIP, self.FOLLOW = UNDEFINED, LIKE, FRIENDSHIP_E, FOLLOW
+        self.MENTION, self.AUTHORSHIP = MENTION, AUTHORSHIP_E
+
+
+def oracle_api():
+    from oracle import rwr_oracle as po
+    return Api(po.Node, po.ForwardLink, po.Graph, lambda g: po.Recommender(g, dense_restart=False), po.NODE_USER,
+               po.NODE_ITEM, po.NODE_ETC, po.EDGE_UNDEFINED, po.EDGE_LIKE, po.EDGE_FRIENDSHIP, po.EDGE_FOLLOW,
+               po.EDGE_MENTION, po.EDGE_AUTHORSHIP)
+
+
+def gpu_api():
+    import recommendersystems_amd as amd
+    N, E = amd.NodeType, amd.EdgeType
+    return Api(amd.Node, amd.ForwardLink, amd.Graph, amd.Recommender, N.USER, N.ITEM, N.ETC, E.UNDEFINED, E.LIKE,
+               E.FRIENDSHIP, E.FOLLOW, E.MENTION, E.AUTHORSHIP)
+
+
+# ------------------------------------------------------------------------------------------------ synthetic <ego>.sqlite
+def make_ego_db(path: str, ego: int = 1000, seed: int = 7, n_friends: int = 55, n_thirdparty: int = 120,
+                n_tweets: int = 900) -> None:
+    """A database in the schema of SQLiteAdapter.cs:30-120 whose ego has >= 50 likes and >= 50 mutual follows
+    (DataLoader.cs:82)."""
+    import random
+    rnd = random.Random(seed)
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    for stmt in ("CREATE TABLE follow(source INTEGER, target INTEGER)", "CREATE TABLE tweet(id INTEGER, author INTEGER)",
+                 "CREATE TABLE retweet(user INTEGER, tweet INTEGER)", "CREATE TABLE quote(user INTEGER, tweet INTEGER)",
+                 "CREATE TABLE favorite(user INTEGER, tweet INTEGER)", "CREATE TABLE mention(source INTEGER, target INTEGER)"):
+        cur.execute(stmt)
+    friends = [ego + 1 + i for i in range(n_friends)]
+    third = [ego + 5000 + i for i in range(n_thirdparty)]
+    members = [ego] + friends
+    for f in friends:                                        # mutual follow = friend
+        cur.execute("INSERT INTO follow VALUES(?,?)", (ego, f))
+        cur.execute("INSERT INTO follow VALUES(?,?)", (f, ego))
+    for m in members:
+        for t in rnd.sample(friends, 6):                     # member -> member follows (some mutual, some not)
+            if t != m:
+                cur.execute("INSERT INTO follow VALUES(?,?)", (m, t))
+        for t in rnd.sample(third, 8):                       # one-directional follows of third-party users
+            cur.execute("INSERT INTO follow VALUES(?,?)", (m, t))
+    tweets = [900000 + 13 * i for i in range(n_tweets)]
+    authors = members + third[:20]
+    for t in tweets:
+        cur.execute("INSERT INTO tweet VALUES(?,?)", (t, rnd.choice(authors)))
+    for m in members:
+        k = 80 if m == ego else rnd.randint(5, 40)
+        liked = rnd.sample(tweets, k)
+        for i, t in enumerate(liked):
+            tbl = ("retweet", "quote", "favorite")[i % 3]
+            cur.execute(f"INSERT INTO {tbl} VALUES(?,?)", (m, t))
+        for t in rnd.sample(liked, 3):                       # the same tweet liked two ways: one like
+            cur.execute("INSERT INTO favorite VALUES(?,?)", (m, t))
+    for m in members:
+        for t in rnd.sample(members, 10):
+            if t != m:
+                for _ in range(rnd.randint(1, 6)):
+                    cur.execute("INSERT INTO mention VALUES(?,?)", (m, t))
+    con.commit()
+    con.close()
+
+
+class SQLiteAdapter:                                         # SQLiteAdapter.cs
+    def __init__(self, path):
+        self.con = sqlite3.connect(path)
+
+    def _set(self, sql):
+        out = {}
+        for (v,) in self.con.execute(sql):
+            out.setdefault(v, None)                          # HashSet<long>, insertion order
+        return list(out)
+
+    def getFollowingUsers(self, u): return self._set(f"SELECT target FROM follow WHERE source = {u}")          # :27-39
+    def getAuthorship(self, u): return self._set(f"SELECT id FROM tweet WHERE author = {u}")                  # :41-53
+    def getRetweets(self, u): return self._set(f"SELECT tweet FROM retweet WHERE user = {u}")                 # :55-67
+    def getQuotedTweets(self, u): return self._set(f"SELECT tweet FROM quote WHERE user = {u}")               # :69-81
+    def getFavoriteTweets(self, u): return self._set(f"SELECT tweet FROM favorite WHERE user = {u}")          # :83-95
+
+    def getMentionCount(self, a, b):                                                                           # :114-125
+        c1 = self.con.execute(f"SELECT COUNT(*) FROM mention WHERE source = {a} AND target = {b}").fetchone()[0]
+        c2 = self.con.execute(f"SELECT COUNT(*) FROM mention WHERE source = {b} AND target = {a}").fetchone()[0]
+        return int(c1) + int(c2)
+
+    def closeDB(self):
+        self.con.close()
+
+
+class DataLoader:                                            # DataLoader.cs
+    def __init__(self, api: Api, db_path: str, ego: int, nFolds: int):
+        self.api, self.egoUserId, self.nFolds = api, ego, nFolds
+        self.db = SQLiteAdapter(db_path)
+        self.allNodes, self.allLinks = {}, {}
+        self.userIDs, self.memberIDs, self.tweetIDs, self.thirdPartyIDs = {}, {}, {}, {}
+        self.nNodes = 0
+        self.testSet = set()
+        self.cntLikesOfEgoUser = 0
+
+    def addUserNode(self, id, type):                         # :38-49
+        if id not in self.userIDs:
+            self.allNodes[self.nNodes] = self.api.Node(id, type)
+            self.userIDs[id] = self.nNodes
+            (self.memberIDs if type == self.api.USER else self.thirdPartyIDs)[id] = self.nNodes
+            self.nNodes += 1
+
+    def addTweetNode(self, id, type):                        # :51-58
+        if id not in self.tweetIDs:
+            self.allNodes[self.nNodes] = self.api.Node(id, type)
+            self.tweetIDs[id] = self.nNodes
+            self.nNodes += 1
+
+    def addLink(self, s, t, type, weight):                   # :60-77: de-duplicated on (target, type)
+        links = self.allLinks.setdefault(s, [])
+        for l in links:
+            if l.targetNode == t and l.type == type:
+                return
+        links.append(self.api.ForwardLink(t, type, weight))
+
+    def _likes(self, user):                                  # :94-108 / :268-280
+        likes = {}
+        for lst in (self.db.getRetweets(user), self.db.getQuotedTweets(user), self.db.getFavoriteTweets(user)):
+            for t in lst:
+                likes.setdefault(t, None)
+        return list(likes)
+
+    def checkEgoNetworkValidation(self):                     # :79-92, :110-120
+        self.cntLikesOfEgoUser = len(self._likes(self.egoUserId))
+        friends = [f for f in self.db.getFollowingUsers(self.egoUserId) if self.egoUserId in self.db.getFollowingUsers(f)]
+        return not (self.cntLikesOfEgoUser < self.nFolds or self.cntLikesOfEgoUser < 50 or len(friends) < 50)
+
+    def splitLikeHistory(self, likes, fold):                 # :122-140: chronological (id-sorted) folds
+        likesList = sorted(likes)
+        unit = len(likes) // self.nFolds
+        lo = unit * fold
+        hi = unit * (fold + 1) if fold < self.nFolds - 1 else len(likes)
+        test = {likesList[i] for i in range(len(likesList)) if lo <= i < hi}
+        train = [likesList[i] for i in range(len(likesList)) if not (lo <= i < hi)]
+        return train, test
+
+    def graphConfiguration(self, methodology, fold):         # :142-254
+        a = self.api
+        features = FEATURES[methodology]
+        self.addUserNode(self.egoUserId, a.USER)             # addMemberNodes, :256-266
+        for f in self.db.getFollowingUsers(self.egoUserId):
+            if self.egoUserId in self.db.getFollowingUsers(f):
+                self.addUserNode(f, a.USER)
+        for member in list(self.memberIDs):                  # addTweetNodesAndLikeEdges, :268-307
+            idx = self.userIDs[member]
+            likes = self._likes(member)
+            if idx == 0:
+                train, self.testSet = self.splitLikeHistory(likes, fold)
+                likes = train
+            for tweet in likes:
+                self.addTweetNode(tweet, a.ITEM)
+                self.addLink(idx, self.tweetIDs[tweet], a.LIKE, 1.0)
+                self.addLink(self.tweetIDs[tweet], idx, a.LIKE, 1.0)
+        incl_friend = FRIENDSHIP in features
+        incl_third = FOLLOWSHIP_ON_THIRDPARTY in features
+        if incl_friend or incl_third:                        # addFollowship, :321-346
+            for member in list(self.memberIDs):
+                idx = self.userIDs[member]
+                for followee in self.db.getFollowingUsers(member):
+                    if followee in self.memberIDs:
+                        if incl_friend:
+                            self.addLink(idx, self.userIDs[followee], a.FRIENDSHIP, 1.0)
+                            self.addLink(self.userIDs[followee], idx, a.FRIENDSHIP, 1.0)
+                    elif incl_third:
+                        self.addUserNode(followee, a.ETC)
+                        self.addLink(idx, self.userIDs[followee], a.FOLLOW, 1.0)
+                        self.addLink(self.userIDs[followee], idx, a.FOLLOW, 1.0)
+        if AUTHORSHIP in features:                           # addAuthorship, :348-363
+            for member in list(self.memberIDs):
+                idx = self.userIDs[member]
+                for tweet in self.db.getAuthorship(member):
+                    if tweet in self.tweetIDs:
+                        self.addLink(idx, self.tweetIDs[tweet], a.AUTHORSHIP, 1.0)
+                        self.addLink(self.tweetIDs[tweet], idx, a.AUTHORSHIP, 1.0)
+        if MENTIONCOUNT in features:                         # addMentionCount2, :398-436
+            for m1 in list(self.memberIDs):
+                idx = self.userIDs[m1]
+                if idx not in self.allLinks:
+                    continue
+                counts, sumLog = {}, 0.0
+                for m2 in self.memberIDs:
+                    if m1 == m2:
+                        continue
+                    c = self.db.getMentionCount(m1, m2)
+                    if c > 1:
+                        counts[self.userIDs[m2]] = c
+                        sumLog += math.log(c)
+                nFriendships = sum(1 for l in self.allLinks[idx] if l.type == a.FRIENDSHIP)
+                if sumLog > 1:
+                    for t, c in counts.items():
+                        self.addLink(idx, t, a.MENTION, nFriendships * math.log(c) / sumLog)
+        self.db.closeDB()
+
+
+def run_k_fold(api: Api, db_path: str, ego: int, methodologies, nFolds: int, nIterations: int, evaluate=None):
+    """Experiment.runKFoldCrossValidation, Experiment.cs:46-155.  Returns the result.dat lines (one per methodology)
+    and, for inspection, the per-fold ranked lists."""
+    lines, lists = [], []
+    for methodology in methodologies:
+        hits_total, ap_total, cntLikes = 0.0, 0.0, 0
+        for fold in range(nFolds):                           # :69
+            loader = DataLoader(api, db_path, ego, nFolds)
+            if fold == 0:
+                if not loader.checkEgoNetworkValidation():
+                    return [], []
+                cntLikes = loader.cntLikesOfEgoUser
+            loader.graphConfiguration(methodology, fold)
+            nodes, edges = loader.allNodes, loader.allLinks
+            if methodology in (INCL_MENTIONCOUNT, EXCL_FRIENDSHIP, INCL_FOLLOWSHIP_ON_THIRDPARTY_AND_MENTIONCOUNT):   # :84-101
+                for forwardLinks in edges.values():
+                    for l in forwardLinks:
+                        if l.type == api.FRIENDSHIP:
+                            l.type = api.UNDEFINED
+            graph = api.Graph(nodes, edges)                  # :104-105
+            graph.buildGraph()
+            recommender = api.Recommender(graph)             # :108-109
+            recommendation = recommender.Recommendation(0, 0.15, nIterations)
+            nHits, sumPrecision = 0, 0.0                     # :121-128
+            for i in range(len(recommendation)):
+                if recommendation[i][0] in loader.testSet:
+                    nHits += 1
+                    sumPrecision += float(nHits) / (i + 1)
+            if evaluate is not None:                         # optional device-side evaluation (section 8f-1)
+                assert evaluate(recommender, loader.testSet, nIterations)[:2] == (nHits, sumPrecision)
+            hits_total += nHits                              # :131-138
+            ap_total += 0 if nHits == 0 else sumPrecision / nHits
+            lists.append((methodology, fold, recommendation))
+            if hasattr(graph, "close"):
+                graph.close()
+        lines.append(f"{ego}\t{methodology}\t{nFolds}\t{nIterations}\t{int(hits_total)}\t{cntLikes}\t{repr(ap_total / nFolds)}")   # :144-153
+    return lines, lists
