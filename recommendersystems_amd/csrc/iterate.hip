@@ -189,11 +189,6 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
 {
     static_assert(G >= 8 && G <= 64, "chunked SpMM needs 8 <= G <= 64");
     constexpr int RPW = WAVE / G;
-    // 512 B of LDS per block that the kernel never needs: it only makes the block non-placeable on a CU whose
-    // whole LDS was claimed by an exact-mode chain workgroup, so that the latency-critical chain keeps its CU's
-    // memory pipeline to itself instead of queueing behind this kernel's gathers
-    __shared__ int lds_token[128];
-    if (n < 0) lds_token[threadIdx.x & 127] = 1;   // never true; keeps the allocation
     const int tile = blockIdx.y;
     const size_t toff = (size_t)tile * (size_t)n * G;
     X += toff;
@@ -487,7 +482,7 @@ __global__ __launch_bounds__(WAVE + CH3_NST) void k_seed_chain_roles(
     int32_t n, const int64_t *__restrict__ in_ptr, const int32_t *__restrict__ in_src,
     const uint8_t *__restrict__ dangling, const double *__restrict__ X, double *__restrict__ Y,
     const int32_t *__restrict__ seeds, double c1, const int64_t *__restrict__ evoff,
-    const double *__restrict__ evterm, uint32_t *__restrict__ nz_out, int dbg, unsigned int *__restrict__ gate)
+    const double *__restrict__ evterm, uint32_t *__restrict__ nz_out, unsigned int *__restrict__ gate)
 {
     // check in: the main stream holds the SpMM back (k_gate) until the chain workgroups own their CUs
     if (threadIdx.x == 0 && gate) __hip_atomic_fetch_add(gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -511,7 +506,6 @@ __global__ __launch_bounds__(WAVE + CH3_NST) void k_seed_chain_roles(
         _Pragma("unroll") for (int u = 0; u < CH3_LPT; ++u) {                   \
             int64_t el = base__ + (int64_t)u * CH3_NST + st;                    \
             el = el < total ? el : total - 1;                                   \
-            if (dbg & 2) el = st;                                               \
             R[u] = x[el];                                                       \
             D[u] = dangling[el / G];                                            \
         }                                                                       \
@@ -576,11 +570,11 @@ __global__ __launch_bounds__(WAVE + CH3_NST) void k_seed_chain_roles(
         // 32-row blocks: all 32 LDS reads are issued up front, the adds consume them in order (each waits only
         // for its own operand), so one LDS latency is exposed per 32 rows.  A block that holds a link into one of
         // the tile's seeds is walked row by row instead (re-reading LDS; deliberately not unrolled).
-        for (int r0 = 0; r0 < ((dbg & 1) ? 32 : CR); r0 += 32) {
+        for (int r0 = 0; r0 < CR; r0 += 32) {
             double v[32];
 #pragma unroll
             for (int u = 0; u < 32; ++u) v[u] = buf[(r0 + u) * G + k];
-            const bool evt = __any(consumer && nxt < row0 + r0 + 32) && !(dbg & 4);
+            const bool evt = __any(consumer && nxt < row0 + r0 + 32);
             if (!evt) {
 #pragma unroll
                 for (int u = 0; u < 32; ++u) acc += v[u];
@@ -713,10 +707,8 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
     }
     if constexpr (G >= 8) {
         if (variant != 0) {
-            // experiment knob: dynamic LDS per block that caps the blocks per CU (0 = no cap)
-            static const size_t occ_lds = [] { const char *e = getenv("RWR_SPMM_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
 #define RWR_SPMM_LAUNCH2(CH, CHK, WR)                                                                              \
-    hipLaunchKernelGGL((k_spmm_chunked<G, CH, CHK, WR>), dim3(gx, tg), dim3(256), occ_lds, s, g->n, g->in_ptr.p,   \
+    hipLaunchKernelGGL((k_spmm_chunked<G, CH, CHK, WR>), dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p,         \
                        g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, nz_in, nz_out, act)
 #define RWR_SPMM_LAUNCH(CH)                                  \
     {                                                        \
@@ -758,18 +750,15 @@ static void launch_chain(rwr_graph *g, int tg, const double *X, double *Y, const
         return;
     }
     static const int variant = [] { const char *e = getenv("RWR_CHAIN"); return e ? atoi(e) : 1; }();   // 0 = simple reference kernel
-    static const int dbg = [] { const char *e = getenv("RWR_CHAIN_DBG"); return e ? atoi(e) : 0; }();
     if (variant != 0) {
-        // with few tiles in flight each chain workgroup claims a whole CU (all 160 KiB of LDS): see k_spmm_chunked
-        static const int excl = [] { const char *e = getenv("RWR_CHAIN_EXCL"); return e ? atoi(e) : 1; }();
-        const size_t smem = (excl && tg <= 64) ? (size_t)160 * 1024 : 2 * CH3_CE * sizeof(double);
+        constexpr size_t smem = 2 * CH3_CE * sizeof(double);
         static const bool attr_ok5 = [] {
             return hipFuncSetAttribute((const void *)k_seed_chain_roles<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024) == hipSuccess;
+                                       (int)smem) == hipSuccess;
         }();
         (void)attr_ok5;
         hipLaunchKernelGGL(k_seed_chain_roles<G>, dim3(tg), dim3(WAVE + CH3_NST), smem, s, g->n, g->in_ptr.p,
-                           g->in_src.p, g->dangling.p, X, Y, seeds, c1, evoff, g->d_evterm.p, nz_out, dbg, gate);
+                           g->in_src.p, g->dangling.p, X, Y, seeds, c1, evoff, g->d_evterm.p, nz_out, gate);
         return;
     }
     hipLaunchKernelGGL(k_seed_chain<G>, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, g->n, tg, g->in_ptr.p,
