@@ -567,39 +567,47 @@ __global__ __launch_bounds__(WAVE + CH3_NST) void k_seed_chain_roles(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         const double *buf = rr + (size_t)(c & 1) * CH3_CE;
         const int64_t row0 = (int64_t)c * CR;
-        // 32-row blocks: all 32 LDS reads are issued up front, the adds consume them in order (each waits only
-        // for its own operand), so one LDS latency is exposed per 32 rows.  A block that holds a link into one of
-        // the tile's seeds is walked row by row instead (re-reading LDS; deliberately not unrolled).
-        for (int r0 = 0; r0 < CR; r0 += 32) {
-            double v[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) v[u] = buf[(r0 + u) * G + k];
-            const bool evt = __any(consumer && nxt < row0 + r0 + 32);
-            if (!evt) {
-#pragma unroll
-                for (int u = 0; u < 32; ++u) acc += v[u];
-            } else {
-                // rare block: same adds from the same registers, but before row u every lane whose pending link
-                // comes from that row takes it first (Model.cs:85-88); the branch is wave-uniformly skipped otherwise
-#pragma unroll
-                for (int u = 0; u < 32; ++u) {
-                    const int32_t i = (int32_t)(row0 + r0) + u;
-                    if (__any(consumer && nxt == i)) {
-                        while (consumer && nxt == i) {
-                            acc += tcur;
-                            nxt = has2 ? raw_s : INT_MAX;  // promote the pending link (loaded at the previous take)
-                            tcur = raw_t;
-                            has2 = p < e;                  // and fetch the one after it; untouched until then
-                            const int64_t pc = has2 ? p : e - 1;
-                            raw_s = srcp[pc];
-                            raw_t = termp[pc];
-                            p += has2 ? 1 : 0;
-                        }
-                    }
-                    acc += v[u];                           // then the restart addend (Model.cs:91-93,96-97)
-                }
-            }
+        // 32-row blocks, two register sets in flight: the 32 LDS reads of the NEXT block are issued before the 32
+        // dependent adds of the current one, so the adds (7.5 cycles each, the chain's floor) never wait for LDS.
+        // A block that holds a link into one of the tile's seeds takes the same adds from the same registers, but
+        // before row u every lane whose pending link comes from that row takes it first (Model.cs:85-88).
+#define CH3_READ(V, R0) _Pragma("unroll") for (int u = 0; u < 32; ++u) V[u] = buf[((R0) + u) * G + k];
+#define CH3_FOLD(V, R0)                                                                                     \
+    {                                                                                                       \
+        const bool evt = __any(consumer && nxt < row0 + (R0) + 32);                                         \
+        if (!evt) {                                                                                         \
+            _Pragma("unroll") for (int u = 0; u < 32; ++u) acc += V[u];                                     \
+        } else {                                                                                            \
+            _Pragma("unroll") for (int u = 0; u < 32; ++u) {                                                \
+                const int32_t i = (int32_t)(row0 + (R0)) + u;                                               \
+                if (__any(consumer && nxt == i)) {                                                          \
+                    while (consumer && nxt == i) {                                                          \
+                        acc += tcur;                                                                        \
+                        nxt = has2 ? raw_s : INT_MAX; /* promote the pending link (loaded at the last take) */ \
+                        tcur = raw_t;                                                                       \
+                        has2 = p < e; /* and fetch the one after it; untouched until then */                \
+                        const int64_t pc = has2 ? p : e - 1;                                                \
+                        raw_s = srcp[pc];                                                                   \
+                        raw_t = termp[pc];                                                                  \
+                        p += has2 ? 1 : 0;                                                                  \
+                    }                                                                                       \
+                }                                                                                           \
+                acc += V[u]; /* then the restart addend (Model.cs:91-93,96-97) */                           \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+        double ra[32], rb[32];
+        CH3_READ(ra, 0)
+#pragma unroll 1
+        for (int r0 = 0; r0 + 64 <= CR; r0 += 64) {
+            CH3_READ(rb, r0 + 32)
+            CH3_FOLD(ra, r0)
+            if (r0 + 64 < CR) CH3_READ(ra, r0 + 64)
+            CH3_FOLD(rb, r0 + 32)
         }
+        if (CR % 64 != 0) CH3_FOLD(ra, CR - 32)        // odd number of 32-row blocks (G = 64): ra already holds the last one
+#undef CH3_READ
+#undef CH3_FOLD
     }
     __builtin_amdgcn_s_setprio(0);
     if (consumer && s >= 0) {
