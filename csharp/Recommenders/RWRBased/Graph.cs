@@ -5,21 +5,6 @@
 using System.Collections.Generic;
 
 namespace Recommenders.RWRBased {
-    public struct Node {
-        public long id;
-        public NodeType type;
-        public Node(long id) { this.id = id; this.type = NodeType.UNDEFINED; }
-        public Node(long id, NodeType type) { this.id = id; this.type = type; }
-    }
-
-    public struct ForwardLink {
-        public int targetNode;
-        public EdgeType type;
-        public double weight;
-        public ForwardLink(int targetNode, double weight) { this.targetNode = targetNode; this.type = EdgeType.UNDEFINED; this.weight = weight; }
-        public ForwardLink(int targetNode, EdgeType type, double weight) { this.targetNode = targetNode; this.type = type; this.weight = weight; }
-    }
-
     public class Graph {
         public Dictionary<int, Node> nodes;
         public Dictionary<int, List<ForwardLink>> edges;
