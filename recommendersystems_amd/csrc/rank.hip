@@ -119,7 +119,9 @@ __global__ __launch_bounds__(256) void k_sel_hist(int32_t n, int32_t n_items, co
                                                   uint32_t *__restrict__ ghist, int level)
 {
     constexpr int RL = 256 / G;
-    __shared__ uint32_t h[G][256];
+    // rows padded to 257 words: at one digit per seed (the usual case at the top levels) the G seeds of a wave would
+    // otherwise all hit LDS bank (digit % 32) -- a G-way conflict on every atomic
+    __shared__ uint32_t h[G][257];
     __shared__ SelState sst[G];
     __shared__ int any_active;
     const int tile = blockIdx.y;
