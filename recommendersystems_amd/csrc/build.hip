@@ -239,6 +239,8 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     g->max_in_deg = h_flags[2];
     g->h_in_ptr.resize((size_t)n + 1);
     RWR_HIP(hipMemcpy(g->h_in_ptr.data(), g->in_ptr.p, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost));
+    g->h_dangling.resize((size_t)n);
+    RWR_HIP(hipMemcpy(g->h_dangling.data(), g->dangling.p, (size_t)n, hipMemcpyDeviceToHost));
     g->bin_end[0] = g->bin_end[1] = g->bin_end[2] = g->bin_huge = 0;
     for (int32_t i = 0; i < n; ++i) {
         const int64_t deg = g->h_in_ptr[i + 1] - g->h_in_ptr[i];

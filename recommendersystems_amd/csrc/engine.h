@@ -25,6 +25,7 @@ struct rwr_graph {
     rwr::DevBuf<uint8_t> etype;
     rwr::DevBuf<double> w_norm_raw;   // Graph.graph weights per raw link (0 for UNDEFINED)
     std::vector<int64_t> h_rowptr;    // host copy (seed validation, exclusion sizing)
+    std::vector<uint8_t> h_dangling;  // host copy of dangling[] (dangling seeds are answered without iterating)
     std::vector<int64_t> h_in_ptr;    // host copy of in_ptr (sizing of the seeds' in-link term buffers)
     // transposed (in-neighbour) CSR of the normalised matrix, entries ordered
     // (source asc, list position asc) = addend order of Model.deliverRanks

@@ -820,6 +820,8 @@ struct EvPool {
 int32_t rank_group_select(rwr_graph *g, int G, int tg, const int32_t *d_slot_k, int32_t top_n, const double *X,
                           const int32_t *d_seeds, hipStream_t s);
 int rank_select_max_k();
+int32_t emit_dangling(rwr_graph *g, const std::vector<int32_t> &rows, const std::vector<int32_t> &seeds, int32_t top_n,
+                      hipStream_t s);
 int32_t rank_tile(rwr_graph *g, int G, const int32_t *d_slot_k_tile, int32_t top_n, const double *X,
                   const int32_t *d_seeds_tile, hipStream_t s);
 
@@ -1041,20 +1043,52 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
             set_error("seed %d (batch position %d) is outside [0, %d)", seeds[k], k, n);
             return RWR_E_RANGE;
         }
+    // dangling seeds (no explicit out-link) are answered directly (see k_emit_dangling); the rest is iterated
+    const int32_t K_all = K;
+    std::vector<int32_t> live_seeds, live_rows, dang_seeds, dang_rows;
+    const bool shortcut = top_n <= rank_select_max_k() && K_all > 1;
+    for (int32_t k = 0; k < K_all; ++k) {
+        if (shortcut && g->h_dangling[seeds[k]]) { dang_seeds.push_back(seeds[k]); dang_rows.push_back(k); }
+        else { live_seeds.push_back(seeds[k]); live_rows.push_back(k); }
+    }
+    const bool any_dangling = !dang_seeds.empty();
+    if (any_dangling) { seeds = live_seeds.data(); K = (int32_t)live_seeds.size(); }
+    hipStream_t s = g->stream;
+    const size_t out_all = (size_t)K_all * (size_t)top_n;
+    RWR_TRY(g->d_out_id.ensure(out_all + 64 * (size_t)top_n));
+    RWR_TRY(g->d_out_score.ensure(out_all + 64 * (size_t)top_n));
+    RWR_TRY(g->d_counts.ensure((size_t)K_all + 64));
+    if (K == 0) {   // every seed of the batch is dangling
+        RWR_TRY(emit_dangling(g, dang_rows, dang_seeds, top_n, s));
+        std::vector<int32_t> hc0((size_t)K_all);
+        RWR_HIP(hipMemcpyAsync(hc0.data(), g->d_counts.p, hc0.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (ids && scores) {
+            RWR_HIP(hipMemcpy2DAsync(ids, (size_t)row_stride * sizeof(int64_t), g->d_out_id.p, (size_t)top_n * sizeof(int64_t),
+                                     (size_t)top_n * sizeof(int64_t), (size_t)K_all, hipMemcpyDeviceToHost, s));
+            RWR_HIP(hipMemcpy2DAsync(scores, (size_t)row_stride * sizeof(double), g->d_out_score.p,
+                                     (size_t)top_n * sizeof(double), (size_t)top_n * sizeof(double), (size_t)K_all,
+                                     hipMemcpyDeviceToHost, s));
+        }
+        RWR_HIP(hipStreamSynchronize(s));
+        for (int32_t k = 0; k < K_all; ++k) counts[k] = hc0[k];
+        g->stats.seeds_done += K_all;
+        g->stats.total_wall_ms += now_ms() - t_begin;
+        return RWR_OK;
+    }
     const int G = resolve_G(g, K);
     int TG = 1;
     RWR_TRY(ensure_workspace(g, G, K, &TG));
     const int ntiles = (int)cdiv((size_t)K, (size_t)G);
-    hipStream_t s = g->stream;
     std::vector<int32_t> slot_k;
     RWR_TRY(upload_seed_slots(g, seeds, K, G, &slot_k));
-    const size_t out_elems = (size_t)ntiles * G * (size_t)top_n;
-    RWR_TRY(g->d_out_id.ensure(out_elems));
-    RWR_TRY(g->d_out_score.ensure(out_elems));
-    RWR_TRY(g->d_counts.ensure((size_t)ntiles * G));
-    RWR_HIP(hipMemsetAsync(g->d_out_id.p, 0, out_elems * sizeof(int64_t), s));
-    RWR_HIP(hipMemsetAsync(g->d_out_score.p, 0, out_elems * sizeof(double), s));
-    RWR_HIP(hipMemsetAsync(g->d_counts.p, 0, (size_t)ntiles * G * sizeof(int32_t), s));
+    if (any_dangling) {   // slots map to positions in the live list: translate to the caller's batch positions
+        for (auto &v : slot_k) if (v >= 0) v = live_rows[v];
+        RWR_HIP(hipMemcpy(g->d_slot_k.p, slot_k.data(), slot_k.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    // output tables are indexed by the caller's batch position (K_all rows)
+    RWR_HIP(hipMemsetAsync(g->d_out_id.p, 0, out_all * sizeof(int64_t), s));
+    RWR_HIP(hipMemsetAsync(g->d_out_score.p, 0, out_all * sizeof(double), s));
+    RWR_HIP(hipMemsetAsync(g->d_counts.p, 0, (size_t)K_all * sizeof(int32_t), s));
 
     EvPool pool;
     std::vector<hipEvent_t> spmm_ev, chain_ev, rank_ev, iter_ev;
@@ -1086,19 +1120,20 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
         }
         if (prof) { RWR_HIP(hipEventRecord(b, s)); rank_ev.push_back(a); rank_ev.push_back(b); }
     }
-    // results: K x top_n (device rows are top_n wide; host rows are row_stride wide)
-    std::vector<int32_t> hc((size_t)ntiles * G);
+    if (any_dangling) RWR_TRY(emit_dangling(g, dang_rows, dang_seeds, top_n, s));
+    // results: K_all x top_n (device rows are top_n wide; host rows are row_stride wide)
+    std::vector<int32_t> hc((size_t)K_all);
     RWR_HIP(hipMemcpyAsync(hc.data(), g->d_counts.p, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (ids && scores) {   // (NULL: the caller consumes the lists on the device, e.g. rwr_recommend_eval)
         RWR_HIP(hipMemcpy2DAsync(ids, (size_t)row_stride * sizeof(int64_t), g->d_out_id.p, (size_t)top_n * sizeof(int64_t),
-                                 (size_t)top_n * sizeof(int64_t), (size_t)K, hipMemcpyDeviceToHost, s));
+                                 (size_t)top_n * sizeof(int64_t), (size_t)K_all, hipMemcpyDeviceToHost, s));
         RWR_HIP(hipMemcpy2DAsync(scores, (size_t)row_stride * sizeof(double), g->d_out_score.p,
-                                 (size_t)top_n * sizeof(double), (size_t)top_n * sizeof(double), (size_t)K,
+                                 (size_t)top_n * sizeof(double), (size_t)top_n * sizeof(double), (size_t)K_all,
                                  hipMemcpyDeviceToHost, s));
     }
     RWR_HIP(hipStreamSynchronize(s));
     RWR_HIP(hipStreamSynchronize(g->stream2));
-    for (int32_t k = 0; k < K; ++k) counts[k] = hc[k];
+    for (int32_t k = 0; k < K_all; ++k) counts[k] = hc[k];
     if (prof) {
         RWR_TRY(drain_events(spmm_ev, &g->stats.spmm_ms));
         RWR_TRY(drain_events(chain_ev, &g->stats.chain_ms));
@@ -1107,7 +1142,7 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
     }
     g->stats.tile_seeds = G;
     g->stats.tile_group = TG;
-    g->stats.seeds_done += K;
+    g->stats.seeds_done += K_all;
     g->stats.total_wall_ms += now_ms() - t_begin;
     return RWR_OK;
 }

@@ -8,6 +8,8 @@
 // padding lane) get the largest key and sort to the end.
 #include "engine.h"
 
+#include <cstdlib>
+
 namespace rwr {
 
 template <int G>
@@ -152,8 +154,10 @@ __global__ __launch_bounds__(256) void k_sel_hist(int32_t n, int32_t n_items, co
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) sv[u] = x[(size_t)row[u] * G + k];
+            int dg[4];                                           // digit of each of the 4 elements, -1 = not counted
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                dg[u] = -1;
                 if (qb + u * RL >= q1) continue;
                 const double s = sv[u];
                 if (!(s >= 0.0)) continue;                       // excluded (Recommender.cs:29)
@@ -161,9 +165,18 @@ __global__ __launch_bounds__(256) void k_sel_hist(int32_t n, int32_t n_items, co
                 uint64_t lo = 0;
                 if (level >= 8) lo = i64_orderable(node_id[row[u]]);
                 if (sel_cmp(hi, lo, my) != 0) continue;
-                const unsigned digit = (level < 8) ? (unsigned)(hi >> (56 - 8 * level)) & 255u
-                                                   : (unsigned)(lo >> (56 - 8 * (level - 8))) & 255u;
-                atomicAdd(&h[k][digit], 1u);
+                dg[u] = (level < 8) ? (int)((hi >> (56 - 8 * level)) & 255u) : (int)((lo >> (56 - 8 * (level - 8))) & 255u);
+            }
+            // equal digits among the 4 (the rule at the top levels, where one exponent byte covers everything) are
+            // counted with ONE LDS atomic: LDS atomics, not the loads, bound this kernel
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (dg[u] < 0) continue;
+                unsigned cnt = 1;
+#pragma unroll
+                for (int v = u + 1; v < 4; ++v)
+                    if (dg[v] == dg[u]) { ++cnt; dg[v] = -1; }
+                atomicAdd(&h[k][dg[u]], cnt);
             }
         }
     }
@@ -449,6 +462,67 @@ int32_t eval_ranked(rwr_graph *g, int32_t cnt, const int64_t *test_sorted_host, 
     RWR_HIP(hipMemcpyAsync(n_hits, d_hits.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     RWR_HIP(hipMemcpyAsync(sum_precision, d_sum.p, sizeof(double), hipMemcpyDeviceToHost, s));
     RWR_HIP(hipStreamSynchronize(s));
+    return RWR_OK;
+}
+
+// A seed without explicit out-links is dangling (Graph.cs:64,86): all of its rank mass returns to it every iteration
+// (Model.cs:94-98), so after ANY number of iterations rank = n at the seed and exactly 0 elsewhere.  Its ranked list is
+// therefore known without iterating: the seed itself first if it is an ITEM (score n; it has no LIKE link, so it is
+// not excluded), then every other item with score +0.0 in id-descending order (Recommender.cs:35-38) = item_order.
+// (Without this shortcut such seeds force the radix select through all 16 digit levels: a 500K-way tie at score 0.)
+__global__ __launch_bounds__(256) void k_emit_dangling(int n_d, const int32_t *__restrict__ d_rows /* batch positions */,
+                                                       const int32_t *__restrict__ d_seed, int32_t n, int32_t n_items,
+                                                       int32_t top_n, const int32_t *__restrict__ item_order,
+                                                       const int64_t *__restrict__ node_id,
+                                                       const uint8_t *__restrict__ node_type, int64_t *__restrict__ out_id,
+                                                       double *__restrict__ out_score, int32_t *__restrict__ out_counts)
+{
+    const int d = blockIdx.y;
+    if (d >= n_d) return;
+    const int32_t orow = d_rows[d], seed = d_seed[d];
+    const bool seed_is_item = node_type[seed] == RWR_NODE_ITEM;
+    const int32_t cnt = top_n < n_items ? top_n : n_items;
+    const int32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q == 0) out_counts[orow] = cnt;
+    if (q >= cnt) return;
+    if (!seed_is_item) {
+        out_id[(size_t)orow * top_n + q] = node_id[item_order[q]];
+        out_score[(size_t)orow * top_n + q] = 0.0;
+        return;
+    }
+    if (q == 0) {
+        out_id[(size_t)orow * top_n] = node_id[seed];
+        out_score[(size_t)orow * top_n] = (double)n;
+        return;
+    }
+    // position of the seed inside item_order (ids are unique): entries before it keep their place, later ones shift by one
+    // -- found by a short scan of the first q entries only
+    int32_t src = q - 1;
+    for (int32_t t = 0; t <= src; ++t)
+        if (item_order[t] == seed) { src = q; break; }
+    out_id[(size_t)orow * top_n + q] = node_id[item_order[src]];
+    out_score[(size_t)orow * top_n + q] = 0.0;
+}
+
+int32_t emit_dangling(rwr_graph *g, const std::vector<int32_t> &rows, const std::vector<int32_t> &seeds, int32_t top_n,
+                      hipStream_t s)
+{
+    const int n_d = (int)rows.size();
+    if (n_d == 0 || g->n_items == 0) return RWR_OK;
+    DevBuf<int32_t> d_rows, d_seed;
+    RWR_TRY(d_rows.alloc(n_d));
+    RWR_TRY(d_seed.alloc(n_d));
+    RWR_HIP(hipMemcpyAsync(d_rows.p, rows.data(), n_d * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    RWR_HIP(hipMemcpyAsync(d_seed.p, seeds.data(), n_d * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    const int32_t cnt = top_n < g->n_items ? top_n : g->n_items;
+    for (int d0 = 0; d0 < n_d; d0 += 65535) {
+        const int nd = n_d - d0 < 65535 ? n_d - d0 : 65535;
+        hipLaunchKernelGGL(k_emit_dangling, dim3(cdiv((size_t)cnt, 256), nd), dim3(256), 0, s, nd, d_rows.p + d0,
+                           d_seed.p + d0, g->n, g->n_items, top_n, g->item_order.p, g->node_id.p, g->node_type.p,
+                           g->d_out_id.p, g->d_out_score.p, g->d_counts.p);
+    }
+    RWR_HIP(hipGetLastError());
+    RWR_HIP(hipStreamSynchronize(s));   // d_rows / d_seed are released on return
     return RWR_OK;
 }
 

@@ -412,3 +412,31 @@ def test_single_seed_fast_mode_vector_spmv(amd, case):
         m.run(10)
         r, _ = F.model_run(po.widen_float(0.15), seed, 0, 10)
         assert np.abs(m.rank - r).max() <= 1e-6 and abs(m.rank.sum() - F.n) < 1e-9 * F.n
+
+
+def test_dangling_seeds_in_a_batch(amd):
+    """Seeds without explicit out-links are answered without iterating (rank = n at the seed, 0 elsewhere, for any T):
+    users with no links, users whose links are all UNDEFINED, and a dangling ITEM seed (which leads its own list)."""
+    rng = np.random.default_rng(4)
+    g = gg.random_graph(91, n_users=60, n_items=300, n_likes=900, n_friend=40)
+    n = len(g["node_id"])
+    # make users 50..59 dangling: relabel all their links UNDEFINED; add two isolated nodes (a user and an item)
+    et = g["etype"].copy()
+    for u in range(50, 60):
+        et[g["rowptr"][u]:g["rowptr"][u + 1]] = gg.EDGE_UNDEFINED
+    node_id = np.concatenate([g["node_id"], [10 ** 12, -77]]).astype(np.int64)
+    node_type = np.concatenate([g["node_type"], [gg.NODE_USER, gg.NODE_ITEM]]).astype(np.uint8)
+    rowptr = np.concatenate([g["rowptr"], [g["rowptr"][-1], g["rowptr"][-1]]]).astype(np.int64)
+    g2 = dict(node_id=node_id, node_type=node_type, rowptr=rowptr, dst=g["dst"], etype=et, w=g["w"])
+    F = FlatGraph(**g2)
+    G = dev_graph(amd, g2)
+    seeds = np.array([0, 55, 3, n, n + 1, 59, 7, 50], dtype=np.int32)        # mix of live and dangling seeds
+    for T in (0, 4):
+        for top_n in (1, 20, 400):
+            ids, sc, cnt = amd.Recommender(G).RecommendationBatch(seeds, 0.15, T, top_n)
+            oi, os_, oc = F.recommend_batch(seeds, 0.15, T, top_n)
+            assert (cnt == oc).all() and (ids == oi).all() and (bits(sc) == bits(os_)).all(), (T, top_n)
+    only = np.array([55, n + 1, 59], dtype=np.int32)                           # a batch of dangling seeds only
+    ids, sc, cnt = amd.Recommender(G).RecommendationBatch(only, 0.15, 6, 10)
+    oi, os_, oc = F.recommend_batch(only, 0.15, 6, 10)
+    assert (cnt == oc).all() and (ids == oi).all() and (bits(sc) == bits(os_)).all()
