@@ -862,7 +862,7 @@ struct GroupIter {
         const size_t elems = (size_t)tg * (size_t)n * G;
         RWR_HIP(hipMemsetAsync(X, 0, elems * sizeof(double), s));
         // frontier bitmaps for the first iterations (chunked SpMM only)
-        static const int nz_iters_env = [] { const char *e = getenv("RWR_NZ_ITERS"); return e ? atoi(e) : 3; }();
+        static const int nz_iters_env = [] { const char *e = getenv("RWR_NZ_ITERS"); return e ? atoi(e) : 4; }();
         static const int spmm_variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
         nz_iters = (G >= 8 && spmm_variant != 0) ? nz_iters_env : 0;
         const size_t nzw = ((size_t)n + 31) / 32;
