@@ -234,7 +234,7 @@ def cpu_baseline(flat, seeds, ids, sc, cnt, args):
     from oracle.c_oracle import FlatGraph, max_threads
     # the GPU box gives one GPU's job a share of 16 host cores (more threads only oversubscribe them)
     cores = min(max_threads(), len(os.sched_getaffinity(0)), args.cpu_threads)
-    ks = args.cpu_seeds or cores
+    ks = args.cpu_seeds or 3 * cores          # ~10-30 s of CPU work on the 100 M-like graph
     ks = min(ks, len(seeds))
     F = FlatGraph(**flat)
     sample = np.ascontiguousarray(seeds[:ks])
