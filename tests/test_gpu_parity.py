@@ -440,3 +440,41 @@ def test_dangling_seeds_in_a_batch(amd):
     ids, sc, cnt = amd.Recommender(G).RecommendationBatch(only, 0.15, 6, 10)
     oi, os_, oc = F.recommend_batch(only, 0.15, 6, 10)
     assert (cnt == oc).all() and (ids == oi).all() and (bits(sc) == bits(os_)).all()
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_hub_nodes_long_rows(amd, mode):
+    """One item liked by every user and one user who likes every item: in-lists of 20 000 / 3 000 entries (long
+    sequential rows, workgroup-per-row bin of the K = 1 vector SpMV, a seed with thousands of in-links for the chain)."""
+    U, I = 20000, 3000
+    rng = np.random.default_rng(12)
+    lists = {i: [] for i in range(U + I)}
+    def like(u, v):
+        lists[u].append(U + v); lists[U + v].append(u)
+    for u in range(U):
+        like(u, 0)                                   # item 0: liked by everyone
+    for v in range(1, I):
+        like(7, v)                                   # user 7: likes everything
+    for _ in range(40000):
+        u, v = int(rng.integers(0, U)), int(rng.integers(1, I))
+        if U + v not in lists[u]:
+            like(u, v)
+    node_id = np.arange(U + I, dtype=np.int64) * 5 + 3
+    node_type = np.array([gg.NODE_USER] * U + [gg.NODE_ITEM] * I, dtype=np.uint8)
+    g = gg._from_lists(node_id, node_type, lists)
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g, mode=mode)
+    rec = amd.Recommender(G)
+    seeds = np.array([7, 0, 19999, 1234] + list(range(100, 128)), dtype=np.int32)
+    ids, sc, cnt = rec.RecommendationBatch(seeds, 0.15, 10, 50)
+    oi, os_, oc = F.recommend_batch(seeds, 0.15, 10, 50)
+    assert (cnt == oc).all() and (ids == oi).all()
+    if mode == "exact":
+        assert (bits(sc) == bits(os_)).all()
+    else:
+        assert np.abs(sc - os_).max() <= 1e-6
+    assert rec.Recommendation(7, 0.15, 10, 50) == []   # user 7 likes every item: nothing left to recommend
+    single = rec.Recommendation(1234, 0.15, 10, 50)    # K = 1 path (fast: vector SpMV with the long-row bin)
+    si, ss = F.recommend(1234, 0.15, 10, 50)
+    assert [r[0] for r in single] == si.tolist() and len(si) == 50
+    assert np.abs(np.array([r[1] for r in single]) - ss).max() <= (0 if mode == "exact" else 1e-6)
