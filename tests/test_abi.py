@@ -63,3 +63,18 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
                 src = open(os.path.join(dp, f), errors="replace").read()
                 assert "rwr_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/rwr.h must be consumable by a C compiler (P/Invoke / cgo / ctypes style bindings assume a C ABI)."""
+    import subprocess
+    src = tmp_path / "use_rwr.c"
+    src.write_text('#include "rwr.h"\n'
+                   'int main(void) { rwr_opts o; rwr_stats s; o.struct_size = (int32_t)sizeof o; s.struct_size = (int32_t)sizeof s;\n'
+                   '  return (int)(rwr_device_count() < 0) + (o.struct_size != 32) + (RWR_NODE_ITEM != 2) + (RWR_EDGE_LIKE != 1); }\n')
+    L = _lib()
+    pkg = os.path.dirname(L.LIB_PATH)
+    exe = tmp_path / "use_rwr"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L" + pkg, "-lrwr", "-Wl,-rpath," + pkg])
+    assert subprocess.run([str(exe)]).returncode == 0
