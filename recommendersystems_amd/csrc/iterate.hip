@@ -760,11 +760,9 @@ static void launch_chain(rwr_graph *g, int tg, const double *X, double *Y, const
     static const int variant = [] { const char *e = getenv("RWR_CHAIN"); return e ? atoi(e) : 1; }();   // 0 = simple reference kernel
     if (variant != 0) {
         constexpr size_t smem = 2 * CH3_CE * sizeof(double);
-        static const bool attr_ok5 = [] {
-            return hipFuncSetAttribute((const void *)k_seed_chain_roles<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)smem) == hipSuccess;
-        }();
-        (void)attr_ok5;
+        // (per launch, not once per process: the attribute belongs to the current device, and one process may hold
+        //  graphs on several devices)
+        (void)hipFuncSetAttribute((const void *)k_seed_chain_roles<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k_seed_chain_roles<G>, dim3(tg), dim3(WAVE + CH3_NST), smem, s, g->n, g->in_ptr.p,
                            g->in_src.p, g->dangling.p, X, Y, seeds, c1, evoff, g->d_evterm.p, nz_out, gate);
         return;

@@ -377,11 +377,8 @@ int32_t rank_group_select(rwr_graph *g, int G, int tg, const int32_t *d_slot_k, 
     }
     RWR_DISPATCH_G(G, hipLaunchKernelGGL(k_sel_collect<GG>, dim3(nblk, tg), dim3(256), 0, s, g->n, m, g->item_rows.p,
                                          g->node_id.p, X, st, d_seeds, cand));
-    static const bool attr_ok = [] {
-        return hipFuncSetAttribute((const void *)k_sel_sort_emit, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   SEL_SLOTS * (int)sizeof(SelCand)) == hipSuccess;
-    }();
-    (void)attr_ok;
+    (void)hipFuncSetAttribute((const void *)k_sel_sort_emit, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              SEL_SLOTS * (int)sizeof(SelCand));   // per launch: the attribute is per device
     hipLaunchKernelGGL(k_sel_sort_emit, dim3(nseg), dim3(256), SEL_SLOTS * sizeof(SelCand), s, d_slot_k, top_n, st, cand,
                        g->d_out_id.p, g->d_out_score.p, g->d_counts.p);
     RWR_HIP(hipGetLastError());
