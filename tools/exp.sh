@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_exp.sh <tag> <env assignments...> -- <bench args...>
+# usage: tools/exp.sh <tag> <env assignments...> -- <bench args...>
 # runs bench.py with the given env and prints a one-line summary
 tag=$1; shift
 envs=()
