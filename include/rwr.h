@@ -76,6 +76,11 @@ typedef struct rwr_opts {
     int32_t profile;         /* 1 = bracket every kernel phase with HIP events (rwr_get_stats)  */
     int64_t workspace_bytes; /* cap on the batch workspace (rank matrices + sort buffers);
                                 0 = auto (a fraction of free HBM)                               */
+    int32_t seed_row_kernel; /* EXACT mode, how the seed's own row (the n-term restart chain,
+                                Model.cs:91-93,96-97) is folded -- every choice is bitwise equal:
+                                0 = auto (env RWR_CHAIN, else by batch size), 1 = sequential fold
+                                beside the SpMM, 2 = parallel binade scan, 3 = simple one-lane loop */
+    int32_t reserved0;
 } rwr_opts;
 
 /* accumulated since creation or the last rwr_reset_stats(); *_ms are device times measured
@@ -101,6 +106,8 @@ typedef struct rwr_stats {
                                 phase (SpMM and seed-row kernels overlapped)                    */
     double  total_wall_ms;   /* host wall time inside rwr_recommend* calls                      */
     int64_t seeds_done;
+    int64_t chain_redo_blocks; /* binade scan: blocks the carry had to redo row by row (binade
+                                  crossings + mispredicted binades), summed over steps and seeds */
 } rwr_stats;
 
 /* ---- library ------------------------------------------------------------------------- */

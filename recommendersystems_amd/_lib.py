@@ -28,7 +28,7 @@ EXPORTS = [
 class rwr_opts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("mode", C.c_int32),
                 ("tile_seeds", C.c_int32), ("tile_group", C.c_int32), ("profile", C.c_int32),
-                ("workspace_bytes", C.c_int64)]
+                ("workspace_bytes", C.c_int64), ("seed_row_kernel", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class rwr_stats(C.Structure):
@@ -37,7 +37,7 @@ class rwr_stats(C.Structure):
                 ("build_ms", C.c_double), ("spmm_ms", C.c_double), ("spmm_launches", C.c_int64),
                 ("spmm_seed_steps", C.c_int64), ("chain_ms", C.c_double), ("chain_launches", C.c_int64),
                 ("rank_ms", C.c_double), ("iterate_wall_ms", C.c_double), ("total_wall_ms", C.c_double),
-                ("seeds_done", C.c_int64)]
+                ("seeds_done", C.c_int64), ("chain_redo_blocks", C.c_int64)]
 
 
 class RwrError(RuntimeError):

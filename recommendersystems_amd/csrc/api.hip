@@ -314,7 +314,7 @@ int32_t rwr_reset_stats(rwr_graph *g)
     if (!g) { set_error("rwr_reset_stats: NULL argument"); return RWR_E_INVALID; }
     rwr_stats &s = g->stats;
     s.spmm_ms = s.chain_ms = s.rank_ms = s.iterate_wall_ms = s.total_wall_ms = 0;
-    s.spmm_launches = s.spmm_seed_steps = s.chain_launches = s.seeds_done = 0;
+    s.spmm_launches = s.spmm_seed_steps = s.chain_launches = s.seeds_done = s.chain_redo_blocks = 0;
     return RWR_OK;
 }
 

@@ -1,0 +1,445 @@
+// EXACT mode, the seed's own row, as a PARALLEL reduction that is still bit-identical to the reference's
+// strictly sequential chain.
+//
+// Model.deliverRanks (Model.cs:76-100) adds into nextRank[seed], for i ascending: i's links into the seed
+// (Model.cs:85-88), then the restart addend  rank[i] - rw  (Model.cs:91-93) or  rank[i]  (dangling,
+// Model.cs:96-97).  That is an n-term fp64 chain  s <- fl(s + a)  per seed; folded literally it runs at the
+// dependent-add latency (k_seed_chain_roles in iterate.hip: ~20 cycles per row, 50 ms per step on a 6 M-node
+// graph), which is hidden behind the SpMM of a large batch but IS the run time of a single-seed call.
+//
+// Binade scan.  All addends are >= 0 (0 <= d <= 1, ranks >= 0), so s only grows.  While s stays inside one
+// binade [2^e, 2^(e+1)), ulp u = 2^(e-52) is constant and s = m*u with an integer m in [2^52, 2^53); then
+//     fl(s + a) = (m + r(a/u)) * u,
+// r = round to nearest integer, an exact half going to the side that makes m + r even.  Inside a binade the
+// chain is therefore an INTEGER sum, except that a half-way addend's increment depends on the parity of the
+// running m: every addend is a function  parity -> increment,  kept as the pair (d0, d1).  These functions
+// compose associatively (PF / pf_compose below), so a block of rows reduces in parallel, in any tree shape, to
+// one (d0, d1); the carry then needs O(1) per block:  m' = m + d[m & 1],  valid iff m' < 2^53 (monotone, so
+// every prefix stayed in the binade too).  A block whose end leaves the binade -- or whose binade was
+// mispredicted -- is redone by one wave with a lane-per-row scan and real fp64 adds at the crossing rows.
+// tests/binade_scan_model.py is an executable model of exactly this arithmetic (checked against sequential
+// sums in tests/test_binade_scan.py); the GPU parity tests compare the kernel with the oracle bit for bit.
+//
+// Pipeline per power-iteration step (all on the main stream, no spinning, no atomics besides the bitmap OR):
+//   k_cs_block<G,false>  plain fp64 sum of each block's addends (any order)            -> approx
+//   k_cs_plan<G>         running approx prefix -> predicted biased exponent per block    -> e_pred
+//   k_cs_block<G,true>   (d0, d1) of each block under its predicted binade             -> d0, d1
+//   k_cs_carry<G>        one wave per tile, lane = seed: carries s through the blocks; cooperative redo of the
+//                        few blocks that cross a binade; writes Y[seed]
+// once per batch: k_cs_links (where each block's share of the seed's in-link list starts).
+#include "engine.h"
+
+namespace rwr {
+
+constexpr int CS_E = 4096;    // rank-matrix elements per block (rows x G)
+constexpr int CS_R = 16;      // rows per thread run
+constexpr unsigned long long CS_HID = 1ull << 52;
+constexpr unsigned long long CS_FRAC = CS_HID - 1ull;
+constexpr long long CS_BIG = 1ll << 53;
+
+struct PF {
+    long long d0, d1;   // increment of m for incoming parity 0 / 1
+};
+
+__device__ __forceinline__ PF pf_of(double a, int eb)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(a);
+    int ea = (int)((b >> 52) & 0x7ff);
+    unsigned long long mant = b & CS_FRAC;
+    if (ea == 0) ea = 1; else mant |= CS_HID;
+    const int sh = eb - ea;
+    PF r;
+    if (mant == 0ull || sh >= 64) {
+        r.d0 = r.d1 = 0;
+    } else if (sh <= 0) {
+        r.d0 = r.d1 = CS_BIG;                       // a >= 2^e: leaves the binade
+    } else {
+        const unsigned long long k = mant >> sh, rem = mant & ((1ull << sh) - 1ull), half = 1ull << (sh - 1);
+        if (rem > half) { r.d0 = r.d1 = (long long)(k + 1ull); }
+        else if (rem == half) { r.d0 = (long long)(k + (k & 1ull)); r.d1 = (long long)(k + ((k + 1ull) & 1ull)); }
+        else { r.d0 = r.d1 = (long long)k; }
+    }
+    return r;
+}
+// first f, then g
+__device__ __forceinline__ PF pf_compose(PF f, PF g)
+{
+    PF r;
+    r.d0 = f.d0 + ((f.d0 & 1) ? g.d1 : g.d0);
+    r.d1 = f.d1 + (((f.d1 + 1) & 1) ? g.d1 : g.d0);
+    r.d0 = r.d0 > CS_BIG ? CS_BIG : r.d0;
+    r.d1 = r.d1 > CS_BIG ? CS_BIG : r.d1;
+    return r;
+}
+__device__ __forceinline__ int cs_pad(int q) { return q + (q >> 4); }
+
+// lnk[slot][c] = number of the seed's in-links whose source row is < c * CH  (c = 0..nchunks)
+__global__ __launch_bounds__(256) void k_cs_links(int nchunks, int CH, const int64_t *__restrict__ in_ptr,
+                                                  const int32_t *__restrict__ in_src,
+                                                  const int32_t *__restrict__ seeds, int32_t *__restrict__ lnk)
+{
+    const int slot = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > nchunks) return;
+    const int32_t s = seeds[slot];
+    int32_t out = 0;
+    if (s >= 0) {
+        const int64_t p0 = in_ptr[s];
+        const int32_t deg = (int32_t)(in_ptr[s + 1] - p0);
+        const int64_t target = (int64_t)c * CH;
+        int32_t lo = 0, hi = deg;
+        while (lo < hi) {
+            const int32_t mid = lo + ((hi - lo) >> 1);
+            if ((int64_t)in_src[p0 + mid] < target) lo = mid + 1; else hi = mid;
+        }
+        out = lo;
+    }
+    lnk[(size_t)slot * (size_t)(nchunks + 1) + c] = out;
+}
+
+// One workgroup per (block of CS_E elements, tile).  The block's restart addends are staged in LDS (coalesced
+// loads); thread (rl, k) then walks its run of CS_R consecutive rows of seed k in row order, taking a row's links
+// into the seed before the row's restart addend; the runs are combined in row order by an LDS tree.
+template <int G, bool FUNCS>
+__global__ __launch_bounds__(256) void k_cs_block(int32_t n, int nchunks, const uint8_t *__restrict__ dangling,
+                                                  const double *__restrict__ X, const int32_t *__restrict__ seeds,
+                                                  double c1, const int64_t *__restrict__ in_ptr,
+                                                  const int32_t *__restrict__ in_src,
+                                                  const int64_t *__restrict__ evoff, const double *__restrict__ evterm,
+                                                  const int32_t *__restrict__ lnk, const int32_t *__restrict__ e_pred,
+                                                  double *__restrict__ approx, long long *__restrict__ od0,
+                                                  long long *__restrict__ od1)
+{
+    constexpr int CH = CS_E / G, RL = 256 / G;
+    static_assert(CH == RL * CS_R, "run length");
+    __shared__ double a_s[CS_E + CS_E / 16];
+    __shared__ long long r0[256], r1[256];
+    const int c = blockIdx.x, tile = blockIdx.y, tid = threadIdx.x;
+    const double *x = X + (size_t)tile * (size_t)n * G;
+    const int64_t row0 = (int64_t)c * CH, el0 = row0 * G, total = (int64_t)n * G;
+#pragma unroll
+    for (int j = 0; j < CS_E / 256; ++j) {
+        const int q = tid + 256 * j;
+        const int64_t el = el0 + q;
+        double a = 0.0;
+        if (el < total) {
+            const double xv = x[el];
+            const double rw = c1 * xv;                       // Model.cs:84
+            a = dangling[el / G] ? xv : (xv - rw);           // Model.cs:97 / :91
+        }
+        a_s[cs_pad(q)] = a;
+    }
+    __syncthreads();
+    const int k = tid % G, rl = tid / G;
+    const int slot = tile * G + k;
+    const int32_t s = seeds[slot];
+    const int64_t ra = row0 + (int64_t)rl * CS_R;
+    int32_t l = 0, l1 = 0;
+    const int32_t *srcp = in_src;
+    const double *termp = evterm;
+    if (s >= 0) {
+        const int32_t *lk = lnk + (size_t)slot * (size_t)(nchunks + 1) + c;
+        const int32_t a0 = lk[0], a1 = lk[1];
+        if (a1 > a0) {
+            srcp = in_src + in_ptr[s];
+            termp = evterm + evoff[slot];
+            int32_t lo = a0, hi = a1;
+            while (lo < hi) {
+                const int32_t mid = lo + ((hi - lo) >> 1);
+                if ((int64_t)srcp[mid] < ra) lo = mid + 1; else hi = mid;
+            }
+            l = lo;
+            l1 = a1;
+        }
+    }
+    const size_t oidx = ((size_t)tile * nchunks + c) * G + k;
+    if constexpr (FUNCS) {
+        const int eb = e_pred[oidx];
+        PF f{0, 0};
+#pragma unroll
+        for (int u = 0; u < CS_R; ++u) {
+            const int64_t row = ra + u;
+            while (l < l1 && (int64_t)srcp[l] == row) { f = pf_compose(f, pf_of(termp[l], eb)); ++l; }   // Model.cs:85-88
+            f = pf_compose(f, pf_of(a_s[cs_pad((rl * CS_R + u) * G + k)], eb));                        // Model.cs:91-93,96-97
+        }
+        r0[tid] = f.d0;
+        r1[tid] = f.d1;
+        __syncthreads();
+        for (int st = 1; st < RL; st <<= 1) {
+            if ((rl & (2 * st - 1)) == 0 && rl + st < RL) {
+                PF a{r0[tid], r1[tid]}, b{r0[tid + st * G], r1[tid + st * G]};
+                const PF r = pf_compose(a, b);
+                r0[tid] = r.d0;
+                r1[tid] = r.d1;
+            }
+            __syncthreads();
+        }
+        if (rl == 0) { od0[oidx] = r0[tid]; od1[oidx] = r1[tid]; }
+    } else {
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < CS_R; ++u) {
+            const int64_t row = ra + u;
+            while (l < l1 && (int64_t)srcp[l] == row) { acc += termp[l]; ++l; }
+            acc += a_s[cs_pad((rl * CS_R + u) * G + k)];
+        }
+        double *racc = reinterpret_cast<double *>(r0);
+        racc[tid] = acc;
+        __syncthreads();
+        for (int st = 1; st < RL; st <<= 1) {
+            if ((rl & (2 * st - 1)) == 0 && rl + st < RL) racc[tid] += racc[tid + st * G];
+            __syncthreads();
+        }
+        if (rl == 0) approx[oidx] = racc[tid];
+    }
+}
+
+// predicted biased exponent of the running sum at the start of every block (from the approximate block sums)
+template <int G>
+__global__ __launch_bounds__(64) void k_cs_plan(int nchunks, const double *__restrict__ approx, int32_t *__restrict__ e_pred)
+{
+    const int tile = blockIdx.x, k = threadIdx.x;
+    if (k >= G) return;
+    const size_t base = (size_t)tile * nchunks * G + k;
+    double pre = 0.0;
+    constexpr int U = 8;
+    for (int c0 = 0; c0 < nchunks; c0 += U) {
+        double ap[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cc = c0 + u < nchunks ? c0 + u : nchunks - 1;
+            ap[u] = approx[base + (size_t)cc * G];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c0 + u < nchunks) {
+                e_pred[base + (size_t)(c0 + u) * G] = (int32_t)(((unsigned long long)__double_as_longlong(pre) >> 52) & 0x7ff);
+                pre += ap[u];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double cs_from_m(int eb, long long M)
+{
+    return __longlong_as_double((long long)(((unsigned long long)eb << 52) | ((unsigned long long)M - CS_HID)));
+}
+
+// One wave redoes block c of seed kk exactly: lane = row, 64 rows at a time; inclusive scan of the rows' parity
+// functions under the CURRENT binade; at the first row that leaves the binade (or while s is zero / subnormal)
+// that row's adds are done in real fp64 and the scan restarts behind it.  Returns the new s (wave-uniform).
+template <int G>
+__device__ double cs_redo_block(double s, int32_t n, int nchunks, int c, int tile, int kk,
+                                const uint8_t *__restrict__ dangling, const double *__restrict__ X,
+                                const int32_t *__restrict__ seeds, double c1, const int64_t *__restrict__ in_ptr,
+                                const int32_t *__restrict__ in_src, const int64_t *__restrict__ evoff,
+                                const double *__restrict__ evterm, const int32_t *__restrict__ lnk)
+{
+    constexpr int CH = CS_E / G;
+    const int lane = threadIdx.x;
+    const int slot = tile * G + kk;
+    const int32_t sd = seeds[slot];
+    const int32_t *lk = lnk + (size_t)slot * (size_t)(nchunks + 1) + c;
+    const int32_t a0 = lk[0], a1 = lk[1];
+    const int32_t *srcp = in_src + in_ptr[sd];
+    const double *termp = evterm + evoff[slot];
+    const double *xk = X + (size_t)tile * (size_t)n * G + kk;
+    for (int sb = 0; sb < CH; sb += WAVE) {
+        const int64_t row = (int64_t)c * CH + sb + lane;
+        const bool inr = (sb + lane < CH) && row < n;
+        double a = 0.0;
+        int32_t lb = 0, le = 0;
+        if (inr) {
+            const double xv = xk[(size_t)row * G];
+            const double rw = c1 * xv;
+            a = dangling[row] ? xv : (xv - rw);
+            if (a1 > a0) {
+                int32_t lo = a0, hi = a1;
+                while (lo < hi) {
+                    const int32_t mid = lo + ((hi - lo) >> 1);
+                    if ((int64_t)srcp[mid] < row) lo = mid + 1; else hi = mid;
+                }
+                lb = le = lo;
+                while (le < a1 && (int64_t)srcp[le] == row) ++le;
+            }
+        }
+        const bool haslink = le > lb;
+        int start = 0;
+        while (start < WAVE) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(s);
+            const int eb = (int)((b >> 52) & 0x7ff);
+            int L;
+            if (eb == 0 || eb == 0x7ff) {
+                // zero / subnormal (or non-finite) running sum: real adds; rows whose addends are all +0.0 are no-ops
+                const unsigned long long nzm = __ballot(lane >= start && (a != 0.0 || haslink));
+                if (!nzm) break;
+                L = __builtin_ctzll(nzm);
+            } else {
+                PF f{0, 0};
+                if (lane >= start) {
+                    for (int32_t q = lb; q < le; ++q) f = pf_compose(f, pf_of(termp[q], eb));
+                    f = pf_compose(f, pf_of(a, eb));
+                }
+#pragma unroll
+                for (int off = 1; off < WAVE; off <<= 1) {
+                    PF o;
+                    o.d0 = __shfl_up(f.d0, off, WAVE);
+                    o.d1 = __shfl_up(f.d1, off, WAVE);
+                    if (lane >= off) f = pf_compose(o, f);
+                }
+                const long long m = (long long)((b & CS_FRAC) | CS_HID);
+                const long long M = m + ((m & 1) ? f.d1 : f.d0);
+                const unsigned long long cross = __ballot(M >= CS_BIG);
+                if (!cross) {
+                    s = cs_from_m(eb, __shfl(M, WAVE - 1, WAVE));
+                    break;
+                }
+                L = __builtin_ctzll(cross);
+                if (L > 0) s = cs_from_m(eb, __shfl(M, L - 1, WAVE));   // rows before the crossing (lanes < start hold m itself)
+            }
+            double t = s;
+            if (lane == L) {
+                for (int32_t q = lb; q < le; ++q) t += termp[q];       // Model.cs:85-88
+                t += a;                                                // Model.cs:91-93,96-97
+            }
+            s = __shfl(t, L, WAVE);
+            start = L + 1;
+        }
+    }
+    return s;
+}
+
+template <int G>
+__global__ __launch_bounds__(64) void k_cs_carry(int32_t n, int nchunks, const uint8_t *__restrict__ dangling,
+                                                 const double *__restrict__ X, double *__restrict__ Y,
+                                                 const int32_t *__restrict__ seeds, double c1,
+                                                 const int64_t *__restrict__ in_ptr, const int32_t *__restrict__ in_src,
+                                                 const int64_t *__restrict__ evoff, const double *__restrict__ evterm,
+                                                 const int32_t *__restrict__ lnk, const double *__restrict__ approx,
+                                                 const int32_t *__restrict__ e_pred, const long long *__restrict__ d0,
+                                                 const long long *__restrict__ d1, uint32_t *__restrict__ nz_out,
+                                                 unsigned long long *__restrict__ redo_count)
+{
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const bool act = lane < G;
+    const int k = act ? lane : 0;
+    const int32_t sd = seeds[tile * G + k];
+    const bool live = act && sd >= 0;
+    const size_t base = (size_t)tile * nchunks * G + k;
+    double s = 0.0;
+    unsigned redo = 0;
+    constexpr int U = 8;
+    for (int c0 = 0; c0 < nchunks; c0 += U) {
+        double ap[U];
+        int32_t ep[U];
+        long long f0[U], f1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cc = c0 + u < nchunks ? c0 + u : nchunks - 1;
+            const size_t idx = base + (size_t)cc * G;
+            ap[u] = approx[idx];
+            ep[u] = e_pred[idx];
+            f0[u] = d0[idx];
+            f1[u] = d1[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c0 + u >= nchunks) break;
+            bool need = false;
+            if (live && ap[u] != 0.0) {                    // (block sum 0 <=> every addend +0.0: s unchanged)
+                const unsigned long long b = (unsigned long long)__double_as_longlong(s);
+                const int eb = (int)((b >> 52) & 0x7ff);
+                need = true;
+                if (eb != 0 && eb == ep[u]) {
+                    const long long m = (long long)((b & CS_FRAC) | CS_HID);
+                    const long long M = m + ((m & 1) ? f1[u] : f0[u]);
+                    if (M < CS_BIG) { s = cs_from_m(eb, M); need = false; }
+                }
+            }
+            unsigned long long mask = __ballot(need);
+            while (mask) {
+                const int kk = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const double sk = __shfl(s, kk, WAVE);
+                const double sn = cs_redo_block<G>(sk, n, nchunks, c0 + u, tile, kk, dangling, X, seeds, c1, in_ptr, in_src,
+                                                   evoff, evterm, lnk);
+                if (lane == kk) { s = sn; ++redo; }
+            }
+        }
+    }
+    if (live) {
+        Y[(size_t)tile * (size_t)n * G + (size_t)sd * G + k] = s;
+        if (nz_out && s != 0.0)
+            atomicOr(&nz_out[(size_t)tile * (((size_t)n + 31) / 32) + ((uint32_t)sd >> 5)], 1u << (sd & 31));
+        if (redo_count && redo) atomicAdd(redo_count, (unsigned long long)redo);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+
+static inline int cs_nchunks(int32_t n, int G) { return (int)(((int64_t)n * G + CS_E - 1) / CS_E); }
+
+#define CS_DISPATCH_G(G, CALL)                            \
+    switch (G) {                                          \
+        case 1: { constexpr int GG = 1; CALL; } break;    \
+        case 2: { constexpr int GG = 2; CALL; } break;    \
+        case 4: { constexpr int GG = 4; CALL; } break;    \
+        case 8: { constexpr int GG = 8; CALL; } break;    \
+        case 16: { constexpr int GG = 16; CALL; } break;  \
+        case 32: { constexpr int GG = 32; CALL; } break;  \
+        default: { constexpr int GG = 64; CALL; } break;  \
+    }
+
+// once per tile group: buffers + the per-block offsets into each seed's in-link list
+int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, hipStream_t s)
+{
+    const int nchunks = cs_nchunks(g->n, G);
+    const size_t cells = (size_t)tg * nchunks * G;
+    RWR_TRY(g->cs_approx.ensure(cells));
+    RWR_TRY(g->cs_e.ensure(cells));
+    RWR_TRY(g->cs_d0.ensure(cells));
+    RWR_TRY(g->cs_d1.ensure(cells));
+    RWR_TRY(g->cs_lnk.ensure((size_t)tg * G * (size_t)(nchunks + 1)));
+    if (!g->cs_redo.p) {
+        RWR_TRY(g->cs_redo.alloc(1));
+        RWR_HIP(hipMemsetAsync(g->cs_redo.p, 0, sizeof(unsigned long long), s));
+    }
+    hipLaunchKernelGGL(k_cs_links, dim3(cdiv((size_t)nchunks + 1, 256), (unsigned)(tg * G)), dim3(256), 0, s, nchunks,
+                       CS_E / G, g->in_ptr.p, g->in_src.p, d_seeds, g->cs_lnk.p);
+    RWR_HIP(hipGetLastError());
+    return RWR_OK;
+}
+
+// one step's seed-row chain for a tile group (the link terms d_evterm must already be on the stream)
+int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,
+                        const int64_t *d_evoff, double c1, uint32_t *nz_out, hipStream_t s)
+{
+    const int nchunks = cs_nchunks(g->n, G);
+    const dim3 grid((unsigned)nchunks, (unsigned)tg);
+    CS_DISPATCH_G(G, hipLaunchKernelGGL((k_cs_block<GG, false>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X,
+                                        d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, g->cs_lnk.p,
+                                        (const int32_t *)nullptr, g->cs_approx.p, (long long *)nullptr, (long long *)nullptr));
+    CS_DISPATCH_G(G, hipLaunchKernelGGL(k_cs_plan<GG>, dim3((unsigned)tg), dim3(64), 0, s, nchunks, g->cs_approx.p, g->cs_e.p));
+    CS_DISPATCH_G(G, hipLaunchKernelGGL((k_cs_block<GG, true>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X,
+                                        d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, g->cs_lnk.p,
+                                        g->cs_e.p, (double *)nullptr, g->cs_d0.p, g->cs_d1.p));
+    CS_DISPATCH_G(G, hipLaunchKernelGGL(k_cs_carry<GG>, dim3((unsigned)tg), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y,
+                                        d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, g->cs_lnk.p,
+                                        g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, nz_out, g->cs_redo.p));
+    RWR_HIP(hipGetLastError());
+    return RWR_OK;
+}
+
+// after the caller has synchronised the stream: fold the redo counter into the statistics
+int32_t chain_scan_collect(rwr_graph *g, hipStream_t s)
+{
+    if (!g->cs_redo.p) return RWR_OK;
+    unsigned long long v = 0;
+    RWR_HIP(hipMemcpyAsync(&v, g->cs_redo.p, sizeof(v), hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipMemsetAsync(g->cs_redo.p, 0, sizeof(v), s));
+    RWR_HIP(hipStreamSynchronize(s));
+    g->stats.chain_redo_blocks += (int64_t)v;
+    return RWR_OK;
+}
+
+}  // namespace rwr

@@ -47,6 +47,13 @@ struct rwr_graph {
     rwr::DevBuf<uint32_t> d_nz;       // [2][tile][ceil(n/32)] bitmaps: row of X / Y has a non-zero (first iterations)
     rwr::DevBuf<int64_t> d_evoff;     // exact mode: per seed slot, offset of its in-link terms in d_evterm
     rwr::DevBuf<double> d_evterm;     // exact mode: ((1-d) x_src) * w of every link INTO a seed, list order
+    // exact mode, parallel seed-row chain (chain_scan.hip): per (tile, block, seed) approximate block sum,
+    // predicted biased exponent, parity-function pair; per (slot, block) offset into the seed's in-link list
+    rwr::DevBuf<double> cs_approx;
+    rwr::DevBuf<int32_t> cs_e;
+    rwr::DevBuf<long long> cs_d0, cs_d1;
+    rwr::DevBuf<int32_t> cs_lnk;
+    rwr::DevBuf<unsigned long long> cs_redo;   // blocks redone by the carry kernel (binade crossings + mispredictions)
     rwr::DevBuf<uint64_t> keys, keys_alt;
     rwr::DevBuf<uint32_t> vals, vals_alt;
     rwr::DevBuf<uint8_t> sort_temp;
@@ -84,5 +91,10 @@ int32_t part_finish_step(rwr_graph *g, double *y, const double *r);
 int32_t part_rank(rwr_graph *g, double *x, int32_t top_n, int64_t *ids, double *scores, int32_t *counts);
 int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double value, double *rank_out,
                   int64_t *iters_out);
+// chain_scan.hip: the exact seed-row chain as a parallel binade scan
+int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, hipStream_t s);
+int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,
+                        const int64_t *d_evoff, double c1, uint32_t *nz_out, hipStream_t s);
+int32_t chain_scan_collect(rwr_graph *g, hipStream_t s);
 
 }  // namespace rwr

@@ -750,15 +750,14 @@ static void launch_seed_terms(rwr_graph *g, int tg, const double *X, const int32
 template <int G>
 static void launch_chain(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
                          const int64_t *evoff, uint32_t *nz_out, unsigned int *gate, hipStream_t s,
-                         const uint32_t *nz_sparse = nullptr)
+                         const uint32_t *nz_sparse, int variant)
 {
     if (nz_sparse) {   // X still sparse: visit only its non-zero rows
         hipLaunchKernelGGL(k_seed_chain_sparse<G>, dim3(tg), dim3(64), 0, s, g->n, g->in_ptr.p, g->in_src.p,
                            g->dangling.p, X, Y, seeds, c1, evoff, g->d_evterm.p, nz_sparse, nz_out, gate);
         return;
     }
-    static const int variant = [] { const char *e = getenv("RWR_CHAIN"); return e ? atoi(e) : 1; }();   // 0 = simple reference kernel
-    if (variant != 0) {
+    if (variant != 0) {   // 0 = simple reference kernel
         constexpr size_t smem = 2 * CH3_CE * sizeof(double);
         // (per launch, not once per process: the attribute belongs to the current device, and one process may hold
         //  graphs on several devices)
@@ -849,6 +848,8 @@ struct GroupIter {
     uint32_t *nz_cur = nullptr, *nz_oth = nullptr;
     int nz_iters = 0;
     int64_t it = 0;
+    bool scan = false;   // exact mode: seed-row chain by the parallel binade scan (chain_scan.hip)
+    int chain_kind = 1;  // 0 simple one-lane loop, 1 auto, 2 scan, 3 role-specialised fold
 
     GroupIter(rwr_graph *g_, int G_, int tg_, const int32_t *seeds, const int64_t *evoff, double d)
         : g(g_), G(G_), tg(tg_), d_seeds(seeds), d_evoff(evoff), c1(1 - d) /* Model.cs:84: (1 - dampingFactor) */,
@@ -871,6 +872,18 @@ struct GroupIter {
         hipLaunchKernelGGL(k_init_seeds, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, X, d_seeds, nz_cur);
         RWR_HIP(hipGetLastError());
         it = 0;
+        // Seed-row chain of the dense iterations.  The role-specialised fold (k_seed_chain_roles) takes ~20 cycles per
+        // row whatever the batch, which a large batch hides behind its SpMM; the binade scan reads X twice but is
+        // parallel, so it wins whenever the SpMM of the group is shorter than the fold: small tile groups, and above
+        // all the single-seed call of the unmodified harness.  RWR_CHAIN: 0 simple kernel, 1 auto, 2 scan, 3 roles.
+        //            opts.seed_row_kernel (1 fold, 2 scan, 3 simple) takes precedence over the environment.
+        static const int chain_env = [] { const char *e = getenv("RWR_CHAIN"); return e ? atoi(e) : 1; }();
+        static const int scan_tg_max = [] { const char *e = getenv("RWR_SCAN_TG"); return e ? atoi(e) : 8; }();
+        const int sel = g->opts.seed_row_kernel;
+        chain_kind = sel == 1 ? 3 : sel == 2 ? 2 : sel == 3 ? 0 : chain_env;
+        scan = g->opts.mode != RWR_MODE_FAST && c1 >= 0.0 && c1 <= 1.0 &&
+               (chain_kind == 2 || (chain_kind == 1 && tg <= scan_tg_max));
+        if (scan) RWR_TRY(chain_scan_prepare(g, G, tg, d_seeds, s));
         return RWR_OK;
     }
 
@@ -900,7 +913,16 @@ struct GroupIter {
                                g->dst.p, g->etype.p);
         }
         if (exact && serial) s2 = s;
-        if (exact) {
+        const bool scan_now = exact && scan && !act;
+        if (scan_now) {
+            // parallel chain on the main stream, ahead of the SpMM (which skips the seed rows)
+            RWR_DISPATCH_G(G, launch_seed_terms<GG>(g, tg, X, d_seeds, c1, d_evoff, s));
+            hipEvent_t c0 = nullptr, c1e = nullptr;
+            if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, s)); }
+            RWR_TRY(chain_scan_step(g, G, tg, X, Y, d_seeds, d_evoff, c1, nz_out, s));
+            if (prof) { RWR_HIP(hipEventRecord(c1e, s)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
+            s2 = s;
+        } else if (exact) {
             // fork: the seed-row chain runs beside the SpMM on the second stream
             RWR_DISPATCH_G(G, launch_seed_terms<GG>(g, tg, X, d_seeds, c1, d_evoff, s));
             gate_it = (use_gate && s2 != s) ? g->d_gate.p + (it % GATE_SLOTS) : nullptr;
@@ -909,7 +931,7 @@ struct GroupIter {
             if (s2 != s) RWR_HIP(hipStreamWaitEvent(s2, g->ev_fork, 0));
             hipEvent_t c0 = nullptr, c1e = nullptr;
             if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, s2)); }
-            RWR_DISPATCH_G(G, launch_chain<GG>(g, tg, X, Y, d_seeds, c1, d_evoff, nz_out, gate_it, s2, act ? nz_in : nullptr));
+            RWR_DISPATCH_G(G, launch_chain<GG>(g, tg, X, Y, d_seeds, c1, d_evoff, nz_out, gate_it, s2, act ? nz_in : nullptr, chain_kind));
             if (prof) { RWR_HIP(hipEventRecord(c1e, s2)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
             RWR_HIP(hipEventRecord(g->ev_join, s2));
         } else {
@@ -918,7 +940,7 @@ struct GroupIter {
             RWR_DISPATCH_G(G, launch_restart_partial<GG>(g, tg, X, c1, s));
             if (prof) { RWR_HIP(hipEventRecord(c1e, s)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
         }
-        if (exact && gate_it) {
+        if (exact && gate_it && !scan_now) {
             const unsigned expected = (unsigned)(tg < 192 ? tg : 192);
             hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, gate_it, expected);
         }
@@ -927,7 +949,7 @@ struct GroupIter {
         RWR_DISPATCH_G(G, launch_spmm<GG>(g, tg, X, Y, d_seeds, c1, exact ? 1 : 0, nz_in, nz_out, s, act));
         if (prof) { RWR_HIP(hipEventRecord(b, s)); spmm_ev.push_back(a); spmm_ev.push_back(b); }
         if (exact) {
-            if (s2 != s) RWR_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
+            if (s2 != s && !scan_now) RWR_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
         } else {
             RWR_DISPATCH_G(G, launch_restart_final<GG>(g, tg, Y, d_seeds, nz_out, s));
         }
@@ -1057,6 +1079,10 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
     RWR_TRY(g->d_out_id.ensure(out_all + 64 * (size_t)top_n));
     RWR_TRY(g->d_out_score.ensure(out_all + 64 * (size_t)top_n));
     RWR_TRY(g->d_counts.ensure((size_t)K_all + 64));
+    // output tables are indexed by the caller's batch position (K_all rows)
+    RWR_HIP(hipMemsetAsync(g->d_out_id.p, 0, out_all * sizeof(int64_t), s));
+    RWR_HIP(hipMemsetAsync(g->d_out_score.p, 0, out_all * sizeof(double), s));
+    RWR_HIP(hipMemsetAsync(g->d_counts.p, 0, (size_t)K_all * sizeof(int32_t), s));
     if (K == 0) {   // every seed of the batch is dangling
         RWR_TRY(emit_dangling(g, dang_rows, dang_seeds, top_n, s));
         std::vector<int32_t> hc0((size_t)K_all);
@@ -1084,10 +1110,6 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
         for (auto &v : slot_k) if (v >= 0) v = live_rows[v];
         RWR_HIP(hipMemcpy(g->d_slot_k.p, slot_k.data(), slot_k.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    // output tables are indexed by the caller's batch position (K_all rows)
-    RWR_HIP(hipMemsetAsync(g->d_out_id.p, 0, out_all * sizeof(int64_t), s));
-    RWR_HIP(hipMemsetAsync(g->d_out_score.p, 0, out_all * sizeof(double), s));
-    RWR_HIP(hipMemsetAsync(g->d_counts.p, 0, (size_t)K_all * sizeof(int32_t), s));
 
     EvPool pool;
     std::vector<hipEvent_t> spmm_ev, chain_ev, rank_ev, iter_ev;
@@ -1133,6 +1155,7 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
     RWR_HIP(hipStreamSynchronize(s));
     RWR_HIP(hipStreamSynchronize(g->stream2));
     for (int32_t k = 0; k < K_all; ++k) counts[k] = hc[k];
+    if (prof) RWR_TRY(chain_scan_collect(g, s));
     if (prof) {
         RWR_TRY(drain_events(spmm_ev, &g->stats.spmm_ms));
         RWR_TRY(drain_events(chain_ev, &g->stats.chain_ms));

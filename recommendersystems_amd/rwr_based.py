@@ -74,14 +74,15 @@ class Graph:
 
     def __init__(self, nodes: Dict[int, Node], edges: Dict[int, List[ForwardLink]], *, mode: Optional[str] = None,
                  device: int = -1, tile_seeds: int = 0, tile_group: int = 0, profile: bool = False,
-                 workspace_bytes: int = 0):
+                 workspace_bytes: int = 0, seed_row_kernel: Optional[str] = None):
         self.nodes = nodes
         self.edges = edges
         self._graph_cache = None
         self._h = C.c_void_p()
         self._opts = _lib.rwr_opts(C.sizeof(_lib.rwr_opts), device,
                                    {None: -1, "exact": _lib.RWR_MODE_EXACT, "fast": _lib.RWR_MODE_FAST}[mode],
-                                   tile_seeds, tile_group, 1 if profile else 0, workspace_bytes)
+                                   tile_seeds, tile_group, 1 if profile else 0, workspace_bytes,
+                                   {None: 0, "auto": 0, "fold": 1, "scan": 2, "simple": 3}[seed_row_kernel], 0)
         self._flat = None
 
     # -- flat constructors (the layout of include/rwr.h), used by the bench for big graphs

@@ -1,0 +1,109 @@
+"""Executable model of the "binade scan" that librwr's parallel exact seed-row chain uses
+(recommendersystems_amd/csrc/chain_scan.hip).  Test infrastructure: pure Python integers, no product code.
+
+Problem: the seed's own row of Model.deliverRanks (Model.cs:85-97) is a strictly sequential fp64 sum of n
+non-negative addends, s <- fl(s + a_i).  While s stays inside one binade [2^e, 2^(e+1)) its unit in the last
+place u = 2^(e-52) is constant, s = m*u with an integer m in [2^52, 2^53), and fl(s + a) = (m + r(a/u))*u where
+r rounds a/u to an integer -- to nearest, and on an exact half to the side that makes m + r even.  So inside a
+binade the sequential sum IS an integer sum, except that a half-way addend's rounding depends on the parity of the
+running m.  Each addend is therefore a function  parity -> increment,  stored as the pair (d0, d1); such
+functions compose associatively, which makes the chain a parallel reduction.  A block is valid only if its end
+stays below 2^53 (then, the addends being non-negative, every prefix did); otherwise the caller falls back to real
+fp64 adds around the crossing.
+"""
+import struct
+
+BIG = 1 << 53
+
+
+def bits(x: float) -> int:
+    return struct.unpack("<Q", struct.pack("<d", x))[0]
+
+
+def from_bits(b: int) -> float:
+    return struct.unpack("<d", struct.pack("<Q", b))[0]
+
+
+def addend_func(a: float, eb: int):
+    """(d0, d1) of addend a >= 0 for a running sum whose biased exponent is eb (a normal number)."""
+    b = bits(a)
+    ea = (b >> 52) & 0x7FF
+    frac = b & ((1 << 52) - 1)
+    if ea == 0:
+        mant, ea = frac, 1          # zero / subnormal: no hidden bit
+    else:
+        mant = frac | (1 << 52)
+    sh = eb - ea
+    if sh <= 0:
+        return (BIG, BIG) if mant else (0, 0)   # a >= 2^e: the sum leaves the binade
+    if sh >= 64:
+        return (0, 0)
+    k = mant >> sh
+    rem = mant & ((1 << sh) - 1)
+    half = 1 << (sh - 1)
+    if rem > half:
+        return (k + 1, k + 1)
+    if rem == half:
+        return (k + (k & 1), k + ((k + 1) & 1))
+    return (k, k)
+
+
+def compose(f, g):
+    """first f, then g"""
+    out = []
+    for p in (0, 1):
+        d = f[p]
+        d2 = d + g[(p + d) & 1]
+        out.append(min(d2, BIG))
+    return tuple(out)
+
+
+def apply_block(s: float, funcs):
+    """s after the block, or None when the block leaves s's binade (caller must fall back)."""
+    b = bits(s)
+    eb = (b >> 52) & 0x7FF
+    assert 0 < eb < 0x7FF
+    m = (b & ((1 << 52) - 1)) | (1 << 52)
+    total = (0, 0)
+    for f in funcs:
+        total = compose(total, f)
+    M = m + total[m & 1]
+    if M >= BIG:
+        return None
+    return from_bits((eb << 52) | (M - (1 << 52)))
+
+
+def chain_sum(addends, block=64):
+    """The whole algorithm: block-wise integer reduction with real fp64 adds at binade crossings."""
+    s = 0.0
+    i, n = 0, len(addends)
+    fallbacks = 0
+    while i < n:
+        eb = (bits(s) >> 52) & 0x7FF
+        if eb == 0:                       # zero or subnormal running sum: real add
+            s = s + addends[i]
+            i += 1
+            continue
+        j = min(n, i + block)
+        funcs = [addend_func(a, eb) for a in addends[i:j]]
+        r = apply_block(s, funcs)
+        if r is not None:
+            s = r
+            i = j
+            continue
+        # crossing inside the block: longest valid prefix, then one real add
+        fallbacks += 1
+        m = (bits(s) & ((1 << 52) - 1)) | (1 << 52)
+        total = (0, 0)
+        q = i
+        while q < j:
+            t2 = compose(total, funcs[q - i])
+            if m + t2[m & 1] >= BIG:
+                break
+            total = t2
+            q += 1
+        M = m + total[m & 1]
+        s = from_bits((eb << 52) | (M - (1 << 52)))
+        s = s + addends[q]                # the crossing add, in real fp64
+        i = q + 1
+    return s, fallbacks

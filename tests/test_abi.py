@@ -30,7 +30,8 @@ def test_header_symbols_exported():
 
 def test_struct_layouts_match_header():
     L = _lib()
-    assert C.sizeof(L.rwr_opts) == 32
+    # the first 32 bytes are the layout the C# shim passes (struct_size = 32); later fields are appended
+    assert C.sizeof(L.rwr_opts) == 40 and L.rwr_opts.workspace_bytes.offset == 24 and L.rwr_opts.seed_row_kernel.offset == 32
     assert L.rwr_stats.nnz_raw.offset == 8 and L.rwr_stats.build_ms.offset == 40
 
 
@@ -71,7 +72,7 @@ def test_header_is_plain_c(tmp_path):
     src = tmp_path / "use_rwr.c"
     src.write_text('#include "rwr.h"\n'
                    'int main(void) { rwr_opts o; rwr_stats s; o.struct_size = (int32_t)sizeof o; s.struct_size = (int32_t)sizeof s;\n'
-                   '  return (int)(rwr_device_count() < 0) + (o.struct_size != 32) + (RWR_NODE_ITEM != 2) + (RWR_EDGE_LIKE != 1); }\n')
+                   '  return (int)(rwr_device_count() < 0) + (o.struct_size != 40) + (RWR_NODE_ITEM != 2) + (RWR_EDGE_LIKE != 1); }\n')
     L = _lib()
     pkg = os.path.dirname(L.LIB_PATH)
     exe = tmp_path / "use_rwr"

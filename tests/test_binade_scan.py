@@ -1,0 +1,67 @@
+"""The integer "binade scan" reproduces a sequential fp64 sum of non-negative addends bit for bit
+(model of the parallel exact seed-row chain; see tests/binade_scan_model.py)."""
+import random
+import struct
+
+from tests.binade_scan_model import addend_func, chain_sum, bits, from_bits
+
+
+def seq_sum(xs):
+    s = 0.0
+    for x in xs:
+        s = s + x
+    return s
+
+
+def test_random_mixed_magnitudes():
+    rng = random.Random(1234)
+    for trial in range(300):
+        n = rng.randint(1, 700)
+        lo, hi = rng.choice([(-40, 10), (-5, 5), (-1074, -1000), (-60, -50), (0, 30)])
+        xs = []
+        for _ in range(n):
+            r = rng.random()
+            if r < 0.15:
+                xs.append(0.0)
+            elif r < 0.25:
+                xs.append(float(2 ** rng.randint(max(lo, -1074), hi)))      # exact powers: ties and exact hits
+            else:
+                xs.append(rng.random() * 2.0 ** rng.randint(lo, hi))
+        got, _ = chain_sum(xs, block=rng.choice([1, 7, 64, 256]))
+        assert bits(got) == bits(seq_sum(xs)), (trial, got, seq_sum(xs))
+
+
+def test_half_way_addends_follow_parity():
+    # s = 2^52 + m (ulp 1): adding x.5 must round to even, which depends on the running parity
+    base = float(2 ** 52)
+    xs = [base] + [0.5] * 50 + [1.5] * 50 + [2.5, 0.5, 3.5] * 20
+    got, fb = chain_sum(xs, block=64)
+    assert bits(got) == bits(seq_sum(xs))
+    xs = [base + 1.0] + [0.5, 1.5] * 100
+    got, fb = chain_sum(xs, block=32)
+    assert bits(got) == bits(seq_sum(xs))
+
+
+def test_rank_like_distribution():
+    # one big value then a long tail of small ones, the shape of an RWR restart chain
+    rng = random.Random(7)
+    n = 20000
+    xs = [6.0e6 * 0.15] + [rng.expovariate(1.0) * 0.15 * rng.choice([1e-9, 1e-3, 1.0]) for _ in range(n)]
+    got, fb = chain_sum(xs, block=256)
+    assert bits(got) == bits(seq_sum(xs))
+    assert fb < 40
+    xs = xs[::-1]
+    got, fb = chain_sum(xs, block=256)
+    assert bits(got) == bits(seq_sum(xs))
+
+
+def test_addend_func_edges():
+    eb = 1023 + 10
+    assert addend_func(0.0, eb) == (0, 0)
+    assert addend_func(2.0 ** 11, eb)[0] >= 1 << 53            # larger than the binade: forces the fall-back
+    u = 2.0 ** (10 - 52)
+    assert addend_func(u, eb) == (1, 1)
+    assert addend_func(u / 2, eb) == (0, 1)                      # exact half: to even
+    assert addend_func(u * 1.5, eb) == (2, 1)
+    assert addend_func(u * 0.75, eb) == (1, 1)
+    assert addend_func(5e-324, eb) == (0, 0)

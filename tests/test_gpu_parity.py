@@ -74,12 +74,13 @@ def test_build_graph_bitwise(amd, case):
 
 @pytest.mark.parametrize("case", SMALL, ids=lambda c: f"g{c['seed']}")
 @pytest.mark.parametrize("tile_seeds", [0, 1, 4, 16, 64])
-def test_small_exact_bitwise_vs_literal_python(amd, case, tile_seeds):
+@pytest.mark.parametrize("seed_row_kernel", ["fold", "scan"])
+def test_small_exact_bitwise_vs_literal_python(amd, case, tile_seeds, seed_row_kernel):
     g = gg.random_graph(**case)
     nodes, edges = po.from_flat(g["node_id"], g["node_type"], g["rowptr"], g["dst"], g["etype"], g["w"])
     PG = po.Graph(nodes, edges)
     PG.buildGraph()
-    G = dev_graph(amd, g, tile_seeds=tile_seeds)
+    G = dev_graph(amd, g, tile_seeds=tile_seeds, seed_row_kernel=seed_row_kernel)
     rec = amd.Recommender(G)
     n = len(nodes)
     for seed in (0, n // 3, case["n_users"] - 1):
@@ -391,6 +392,67 @@ def test_degenerate_graphs(amd):
     assert amd.Recommender(G).Recommendation(0, 0.15, 5) == [(40, 0.0), (30, 0.0), (20, 0.0)]
     ids, sc, cnt = amd.Recommender(G).RecommendationBatch(np.array([0, 0], dtype=np.int32), 0.15, 5, 2)
     assert ids.tolist() == [[40, 30], [40, 30]] and cnt.tolist() == [2, 2]
+    # a batch whose seeds are all dangling on a graph WITHOUT items: empty lists, counts 0 (not stale memory)
+    g = gg._from_lists(np.array([0], dtype=np.int64), np.array([gg.NODE_UNDEFINED], dtype=np.uint8), {0: []})
+    G = dev_graph(amd, g)
+    ids, sc, cnt = amd.Recommender(G).RecommendationBatch(np.array([0, 0, 0], dtype=np.int32), 0.15, 1, 5)
+    assert cnt.tolist() == [0, 0, 0]
+
+
+@pytest.mark.parametrize("tile_seeds", [1, 8, 32])
+def test_seed_row_binade_scan_bitwise(amd, tile_seeds):
+    """The parallel form of the seed-row chain (chain_scan.hip) on a graph large enough for many blocks per seed, with
+    weights spanning 60 binades (half-way addends, tiny addends that vanish, addends larger than the running sum), hub
+    seeds with thousands of in-links and dangling rows; bitwise against the C restatement, and against the sequential
+    fold kernel; the carry must have redone some blocks (binade crossings) but not all of them."""
+    rng = np.random.default_rng(99)
+    U, I = 30000, 50000
+    n = U + I
+    lists = {i: [] for i in range(n)}
+    wl = {i: [] for i in range(n)}
+    def link(a, b, w):
+        lists[a].append(b); wl[a].append(w)
+    us = (rng.random(300000) ** 2 * U).astype(np.int64)
+    vs = (rng.random(300000) ** 3 * I).astype(np.int64)
+    seen = set()
+    for u, v in zip(us.tolist(), vs.tolist()):
+        if (u, v) in seen:
+            continue
+        seen.add((u, v))
+        w = float(2.0 ** rng.integers(-30, 30)) if rng.random() < 0.5 else float(rng.random() * 2.0 ** rng.integers(-30, 30))
+        link(u, U + v, w)
+        link(U + v, u, 1.0)
+    for u in range(0, 3000):                                     # hub seed 5: thousands of in-links
+        link(U + (u * 7) % I, 5, 0.5)
+    node_id = rng.permutation(n).astype(np.int64) * 3 - 1000
+    node_type = np.array([gg.NODE_USER] * U + [gg.NODE_ITEM] * I, dtype=np.uint8)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    for i in range(n):
+        rowptr[i + 1] = rowptr[i] + len(lists[i])
+    dst = np.fromiter((t for i in range(n) for t in lists[i]), dtype=np.int32, count=int(rowptr[n]))
+    w = np.fromiter((x for i in range(n) for x in wl[i]), dtype=np.float64, count=int(rowptr[n]))
+    g = dict(node_id=node_id, node_type=node_type, rowptr=rowptr, dst=dst, etype=np.full(len(dst), gg.EDGE_LIKE, dtype=np.uint8), w=w)
+    F = FlatGraph(**g)
+    K = {1: 1, 8: 11, 32: 70}[tile_seeds]
+    seeds = np.unique(np.concatenate([[5, 0, U - 1], rng.integers(0, U, K)]))[:max(K, 1)].astype(np.int32)
+    if tile_seeds == 1:
+        seeds = np.array([5], dtype=np.int32)
+    oi, os_, oc = F.recommend_batch(seeds, 0.15, 7, 30)
+    outs = {}
+    for kern in ("scan", "fold"):
+        G = dev_graph(amd, g, tile_seeds=tile_seeds, seed_row_kernel=kern, profile=True)
+        ids, sc, cnt = amd.Recommender(G).RecommendationBatch(seeds, 0.15, 7, 30)
+        assert (cnt == oc).all() and (ids == oi).all() and (bits(sc) == bits(os_)).all(), kern
+        for sd in seeds[:2]:
+            m = amd.Model(G, po.widen_float(0.15), int(sd))
+            m.run(7)
+            r, _ = F.model_run(po.widen_float(0.15), int(sd), 0, 7)
+            assert (bits(m.rank) == bits(r)).all(), (kern, int(sd))
+        outs[kern] = G.stats()["chain_redo_blocks"]
+        G.close()
+    nblocks = -(-n * tile_seeds // 4096)
+    assert outs["fold"] == 0
+    assert 0 < outs["scan"] < 0.5 * nblocks * len(seeds) * 7, outs
 
 
 @pytest.mark.parametrize("case", SMALL[:2] + MEDIUM, ids=lambda c: f"g{c['seed']}")
