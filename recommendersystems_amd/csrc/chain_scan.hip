@@ -22,11 +22,14 @@
 //
 // Pipeline per power-iteration step (all on the main stream, no spinning, no atomics besides the bitmap OR):
 //   k_cs_block<G,false>  plain fp64 sum of each block's addends (any order)            -> approx
-//   k_cs_plan<G>         running approx prefix -> predicted biased exponent per block    -> e_pred
+//   k_cs_plan            running approx prefix -> predicted biased exponent per block    -> e_pred
 //   k_cs_block<G,true>   (d0, d1) of each block under its predicted binade             -> d0, d1
-//   k_cs_carry<G>        one wave per tile, lane = seed: carries s through the blocks; cooperative redo of the
-//                        few blocks that cross a binade; writes Y[seed]
+//   k_cs_carry<G>        one wave per seed, lane = block: the block functions of a 64-block window are themselves
+//                        composed by a wave scan; the window is accepted up to the first block that leaves the
+//                        binade (or whose binade was mispredicted), that block is redone row by row by the same
+//                        wave, and the carry goes on behind it; writes Y[seed]
 // once per batch: k_cs_links (where each block's share of the seed's in-link list starts).
+// Per-(seed, block) cells are laid out [slot][block] so that a window is one coalesced load.
 #include "engine.h"
 
 namespace rwr {
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void k_cs_block(int32_t n, int nchunks, const 
             l1 = a1;
         }
     }
-    const size_t oidx = ((size_t)tile * nchunks + c) * G + k;
+    const size_t oidx = (size_t)slot * nchunks + c;
     if constexpr (FUNCS) {
         const int eb = e_pred[oidx];
         PF f{0, 0};
@@ -194,29 +197,29 @@ __global__ __launch_bounds__(256) void k_cs_block(int32_t n, int nchunks, const 
     }
 }
 
-// predicted biased exponent of the running sum at the start of every block (from the approximate block sums)
-template <int G>
-__global__ __launch_bounds__(64) void k_cs_plan(int nchunks, const double *__restrict__ approx, int32_t *__restrict__ e_pred)
+// predicted biased exponent of the running sum at the start of every block (from the approximate block sums);
+// one wave per seed, 64 blocks per step: shuffle scan of the block sums (any association will do for a prediction)
+__global__ __launch_bounds__(64) void k_cs_plan(int nchunks, const int32_t *__restrict__ seeds,
+                                                const double *__restrict__ approx, int32_t *__restrict__ e_pred)
 {
-    const int tile = blockIdx.x, k = threadIdx.x;
-    if (k >= G) return;
-    const size_t base = (size_t)tile * nchunks * G + k;
-    double pre = 0.0;
-    constexpr int U = 8;
-    for (int c0 = 0; c0 < nchunks; c0 += U) {
-        double ap[U];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    if (seeds[slot] < 0) return;
+    const size_t base = (size_t)slot * nchunks;
+    double carry = 0.0;
+    for (int c0 = 0; c0 < nchunks; c0 += WAVE) {
+        const int c = c0 + lane;
+        const double ap = c < nchunks ? approx[base + c] : 0.0;
+        double incl = ap;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int cc = c0 + u < nchunks ? c0 + u : nchunks - 1;
-            ap[u] = approx[base + (size_t)cc * G];
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const double o = __shfl_up(incl, off, WAVE);
+            if (lane >= off) incl += o;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (c0 + u < nchunks) {
-                e_pred[base + (size_t)(c0 + u) * G] = (int32_t)(((unsigned long long)__double_as_longlong(pre) >> 52) & 0x7ff);
-                pre += ap[u];
-            }
-        }
+        double excl = __shfl_up(incl, 1, WAVE);
+        if (lane == 0) excl = 0.0;
+        const double pre = carry + excl;
+        if (c < nchunks) e_pred[base + c] = (int32_t)(((unsigned long long)__double_as_longlong(pre) >> 52) & 0x7ff);
+        carry += __shfl(incl, WAVE - 1, WAVE);
     }
 }
 
@@ -320,54 +323,62 @@ __global__ __launch_bounds__(64) void k_cs_carry(int32_t n, int nchunks, const u
                                                  const long long *__restrict__ d1, uint32_t *__restrict__ nz_out,
                                                  unsigned long long *__restrict__ redo_count)
 {
-    const int tile = blockIdx.x, lane = threadIdx.x;
-    const bool act = lane < G;
-    const int k = act ? lane : 0;
-    const int32_t sd = seeds[tile * G + k];
-    const bool live = act && sd >= 0;
-    const size_t base = (size_t)tile * nchunks * G + k;
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    const int tile = slot / G, k = slot % G;
+    const int32_t sd = seeds[slot];
+    if (sd < 0) return;                                   // padding slot (whole wave)
+    const size_t base = (size_t)slot * nchunks;
     double s = 0.0;
     unsigned redo = 0;
-    constexpr int U = 8;
-    for (int c0 = 0; c0 < nchunks; c0 += U) {
-        double ap[U];
-        int32_t ep[U];
-        long long f0[U], f1[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int cc = c0 + u < nchunks ? c0 + u : nchunks - 1;
-            const size_t idx = base + (size_t)cc * G;
-            ap[u] = approx[idx];
-            ep[u] = e_pred[idx];
-            f0[u] = d0[idx];
-            f1[u] = d1[idx];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (c0 + u >= nchunks) break;
-            bool need = false;
-            if (live && ap[u] != 0.0) {                    // (block sum 0 <=> every addend +0.0: s unchanged)
-                const unsigned long long b = (unsigned long long)__double_as_longlong(s);
-                const int eb = (int)((b >> 52) & 0x7ff);
-                need = true;
-                if (eb != 0 && eb == ep[u]) {
-                    const long long m = (long long)((b & CS_FRAC) | CS_HID);
-                    const long long M = m + ((m & 1) ? f1[u] : f0[u]);
-                    if (M < CS_BIG) { s = cs_from_m(eb, M); need = false; }
-                }
-            }
-            unsigned long long mask = __ballot(need);
-            while (mask) {
-                const int kk = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const double sk = __shfl(s, kk, WAVE);
-                const double sn = cs_redo_block<G>(sk, n, nchunks, c0 + u, tile, kk, dangling, X, seeds, c1, in_ptr, in_src,
-                                                   evoff, evterm, lnk);
-                if (lane == kk) { s = sn; ++redo; }
-            }
-        }
+    // window registers: (block sum, predicted exponent, d0, d1) of block c + lane
+    double ap, apn = 0.0;
+    int32_t ep, epn = 0;
+    long long f0, f1, f0n = 0, f1n = 0;
+#define CS_LOAD(C, AP, EP, F0, F1)                                   \
+    {                                                                \
+        const int cc__ = (C) + lane;                                 \
+        const bool v__ = cc__ < nchunks;                             \
+        const size_t i__ = base + (v__ ? cc__ : nchunks - 1);        \
+        AP = v__ ? approx[i__] : 0.0;                                \
+        EP = e_pred[i__];                                            \
+        F0 = d0[i__];                                                \
+        F1 = d1[i__];                                                \
     }
-    if (live) {
+    int c = 0;
+    CS_LOAD(0, ap, ep, f0, f1)
+    while (c < nchunks) {
+        if (c + WAVE < nchunks) CS_LOAD(c + WAVE, apn, epn, f0n, f1n)   // the next window, should this one be accepted whole
+        const unsigned long long b = (unsigned long long)__double_as_longlong(s);
+        const int eb = (int)((b >> 52) & 0x7ff);
+        const bool normal = eb != 0 && eb != 0x7ff;
+        const bool nz = ap != 0.0;                        // (block sum 0 <=> every addend +0.0: the block is a no-op)
+        PF f{0, 0};
+        if (nz) { f.d0 = f0; f.d1 = f1; }
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            PF o;
+            o.d0 = __shfl_up(f.d0, off, WAVE);
+            o.d1 = __shfl_up(f.d1, off, WAVE);
+            if (lane >= off) f = pf_compose(o, f);
+        }
+        const long long m = (long long)((b & CS_FRAC) | CS_HID);
+        const long long M = m + ((m & 1) ? f.d1 : f.d0);
+        const unsigned long long bad = __ballot(nz && (!normal || ep != eb || M >= CS_BIG));
+        if (!bad) {
+            if (normal) s = cs_from_m(eb, __shfl(M, WAVE - 1, WAVE));
+            c += WAVE;
+            ap = apn; ep = epn; f0 = f0n; f1 = f1n;
+            continue;
+        }
+        const int L = __builtin_ctzll(bad);
+        if (L > 0 && normal) s = cs_from_m(eb, __shfl(M, L - 1, WAVE));   // the blocks before it
+        s = cs_redo_block<G>(s, n, nchunks, c + L, tile, k, dangling, X, seeds, c1, in_ptr, in_src, evoff, evterm, lnk);
+        ++redo;
+        c += L + 1;
+        if (c < nchunks) CS_LOAD(c, ap, ep, f0, f1)
+    }
+#undef CS_LOAD
+    if (lane == 0) {
         Y[(size_t)tile * (size_t)n * G + (size_t)sd * G + k] = s;
         if (nz_out && s != 0.0)
             atomicOr(&nz_out[(size_t)tile * (((size_t)n + 31) / 32) + ((uint32_t)sd >> 5)], 1u << (sd & 31));
@@ -419,11 +430,11 @@ int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y,
     CS_DISPATCH_G(G, hipLaunchKernelGGL((k_cs_block<GG, false>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X,
                                         d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, g->cs_lnk.p,
                                         (const int32_t *)nullptr, g->cs_approx.p, (long long *)nullptr, (long long *)nullptr));
-    CS_DISPATCH_G(G, hipLaunchKernelGGL(k_cs_plan<GG>, dim3((unsigned)tg), dim3(64), 0, s, nchunks, g->cs_approx.p, g->cs_e.p));
+    hipLaunchKernelGGL(k_cs_plan, dim3((unsigned)(tg * G)), dim3(64), 0, s, nchunks, d_seeds, g->cs_approx.p, g->cs_e.p);
     CS_DISPATCH_G(G, hipLaunchKernelGGL((k_cs_block<GG, true>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X,
                                         d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, g->cs_lnk.p,
                                         g->cs_e.p, (double *)nullptr, g->cs_d0.p, g->cs_d1.p));
-    CS_DISPATCH_G(G, hipLaunchKernelGGL(k_cs_carry<GG>, dim3((unsigned)tg), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y,
+    CS_DISPATCH_G(G, hipLaunchKernelGGL(k_cs_carry<GG>, dim3((unsigned)(tg * G)), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y,
                                         d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, g->cs_lnk.p,
                                         g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, nz_out, g->cs_redo.p));
     RWR_HIP(hipGetLastError());

@@ -878,11 +878,15 @@ struct GroupIter {
         // all the single-seed call of the unmodified harness.  RWR_CHAIN: 0 simple kernel, 1 auto, 2 scan, 3 roles.
         //            opts.seed_row_kernel (1 fold, 2 scan, 3 simple) takes precedence over the environment.
         static const int chain_env = [] { const char *e = getenv("RWR_CHAIN"); return e ? atoi(e) : 1; }();
-        static const int scan_tg_max = [] { const char *e = getenv("RWR_SCAN_TG"); return e ? atoi(e) : 8; }();
+        // auto: per step the fold costs ~10 ns per node whatever the batch (hidden if the SpMM is longer); the scan
+        // costs ~6.7 ps per (node, seed) on top of an SpMM of ~0.89 ps per (link, seed)  (measured, MI355X, 20 M- and
+        // 200 M-link graphs) => scan while  seeds * (0.89 * links/node + 6.7) < 10000  (about 280 seeds there)
+        static const double scan_work = [] { const char *e = getenv("RWR_SCAN_WORK"); return e ? atof(e) : 10000.0; }();
         const int sel = g->opts.seed_row_kernel;
         chain_kind = sel == 1 ? 3 : sel == 2 ? 2 : sel == 3 ? 0 : chain_env;
+        const double per_seed = 0.89 * (double)g->nnz / (double)(g->n > 0 ? g->n : 1) + 6.7;
         scan = g->opts.mode != RWR_MODE_FAST && c1 >= 0.0 && c1 <= 1.0 &&
-               (chain_kind == 2 || (chain_kind == 1 && tg <= scan_tg_max));
+               (chain_kind == 2 || (chain_kind == 1 && (double)tg * G * per_seed < scan_work));
         if (scan) RWR_TRY(chain_scan_prepare(g, G, tg, d_seeds, s));
         return RWR_OK;
     }
