@@ -11,6 +11,7 @@ namespace Recommenders.RWRBased {
         Dictionary<int, ForwardLink[]> normalized;        // materialised lazily from the device
         internal GraphHandle handle;
         long[] rowptr; int[] dst; byte[] etype;
+        long[] sentId; byte[] sentType; double[] sentW;   // what the device currently holds (for incremental rebuilds)
 
         public Graph(Dictionary<int, Node> nodes, Dictionary<int, List<ForwardLink>> edges) {
             this.nodes = nodes;
@@ -20,6 +21,7 @@ namespace Recommenders.RWRBased {
         public void buildGraph() {
             int n = nodes.Count;
             var id = new long[n]; var type = new byte[n];
+            long[] prevRowptr = rowptr; int[] prevDst = dst; byte[] prevEtype = etype;
             rowptr = new long[n + 1];
             for (int i = 0; i < n; i++) {
                 id[i] = nodes[i].id; type[i] = (byte)nodes[i].type;
@@ -32,9 +34,30 @@ namespace Recommenders.RWRBased {
                 if (!edges.ContainsKey(i)) continue;
                 foreach (ForwardLink l in edges[i]) { dst[e] = l.targetNode; etype[e] = (byte)l.type; w[e] = l.weight; e++; }
             }
-            var opts = new RwrOpts { struct_size = 32, device = -1, mode = -1 };
-            Native.Check(Native.rwr_graph_create(n, id, type, rowptr, dst, etype, w, ref opts, out handle));
             normalized = null;
+            // buildGraph() called again on the same object after the host mutated link types or weights in place
+            // (Experiment.cs:84-101 relabels FRIENDSHIP -> UNDEFINED): same nodes, same list lengths, same targets
+            // => send only the links that differ (rwr_graph_update_links); the device state is identical either way.
+            if (handle != null && !handle.IsInvalid && sentW != null && SameTopology(id, type, prevRowptr, prevDst)) {
+                var idx = new List<long>(); var nt = new List<byte>(); var nw = new List<double>();
+                for (long p = 0; p < m; p++)
+                    if (etype[p] != prevEtype[p] || System.BitConverter.DoubleToInt64Bits(w[p]) != System.BitConverter.DoubleToInt64Bits(sentW[p])) {
+                        idx.Add(p); nt.Add(etype[p]); nw.Add(w[p]);
+                    }
+                Native.Check(Native.rwr_graph_update_links(handle, idx.Count, idx.ToArray(), nt.ToArray(), nw.ToArray()));
+            } else {
+                var opts = new RwrOpts { struct_size = 32, device = -1, mode = -1 };
+                Native.Check(Native.rwr_graph_create(n, id, type, rowptr, dst, etype, w, ref opts, out handle));
+            }
+            sentId = id; sentType = type; sentW = w;
+        }
+
+        bool SameTopology(long[] id, byte[] type, long[] oldRowptr, int[] oldDst) {
+            if (oldRowptr == null || oldRowptr.Length != rowptr.Length || oldDst.Length != dst.Length) return false;
+            for (int i = 0; i < rowptr.Length; i++) if (oldRowptr[i] != rowptr[i]) return false;
+            for (long p = 0; p < dst.LongLength; p++) if (oldDst[p] != dst[p]) return false;
+            for (int i = 0; i < id.Length; i++) if (sentId[i] != id[i] || sentType[i] != type[i]) return false;
+            return true;
         }
 
         // public field of the reference (Graph.cs:43), served as a property backed by the device copy

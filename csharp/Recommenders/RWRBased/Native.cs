@@ -24,6 +24,8 @@ namespace Recommenders.RWRBased {
         [DllImport(Lib)] public static extern int rwr_device_count();
         [DllImport(Lib)] public static extern int rwr_graph_create(int n, long[] node_id, byte[] node_type, long[] rowptr,
             int[] dst, byte[] etype, double[] w, ref RwrOpts opts, out GraphHandle g);
+        [DllImport(Lib)] public static extern int rwr_graph_update_links(GraphHandle g, long count, long[] link_index,
+            byte[] etype, double[] w);
         [DllImport(Lib)] public static extern int rwr_graph_destroy(IntPtr g);
         [DllImport(Lib)] public static extern int rwr_graph_get_normalized(GraphHandle g, double[] w_out, byte[] dangling_out);
         [DllImport(Lib)] public static extern int rwr_recommend(GraphHandle g, int seed, float d, int n_iter, int top_n,

@@ -138,6 +138,19 @@ int32_t rwr_graph_create(int32_t n, const int64_t *node_id, const uint8_t *node_
                          const int64_t *rowptr /* n+1 */, const int32_t *dst, const uint8_t *etype,
                          const double *w, const rwr_opts *opts /* may be NULL */, rwr_graph **out);
 int32_t rwr_graph_destroy(rwr_graph *g);
+/* Incremental rebuild.  The harness builds an almost identical graph for every fold and
+ * methodology (new DataLoader + new Graph + buildGraph per fold, Experiment.cs:69-77,104-105),
+ * and three methodologies differ from their base only by relabelling FRIENDSHIP links to
+ * UNDEFINED (Experiment.cs:84-101).  When node list, rowptr and dst are unchanged, only the
+ * links whose type or weight differ need to cross the boundary: link_index[q] is a position
+ * in the flattened raw list given to rwr_graph_create (distinct positions), etype[q] / w[q]
+ * its new type / raw weight (either array may be NULL = unchanged).  The library patches its
+ * resident raw lists and re-runs Graph.buildGraph (Graph.cs:51-88) and the transpose on the
+ * device; the resulting state is bit for bit what rwr_graph_create would build from the
+ * patched lists.  count == 0 just rebuilds.  Not to be called concurrently with other calls
+ * on the same handle. */
+int32_t rwr_graph_update_links(rwr_graph *g, int64_t count, const int64_t *link_index,
+                               const uint8_t *etype /* may be NULL */, const double *w /* may be NULL */);
 /* Graph.size() (Graph.cs:91-93) plus link counts; any out pointer may be NULL */
 int32_t rwr_graph_size(const rwr_graph *g, int32_t *n, int64_t *nnz_raw, int64_t *nnz_explicit);
 /* Backs the public field Graph.graph (Graph.cs:43): w_out[e] = normalised weight of raw

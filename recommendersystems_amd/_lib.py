@@ -18,7 +18,7 @@ RWR_RUN_ITERATIONS, RWR_RUN_THRESHOLD, RWR_RUN_DEFAULT_THRESHOLD = 0, 1, 2
 # every symbol include/rwr.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "rwr_version", "rwr_device_count", "rwr_last_error",
-    "rwr_graph_create", "rwr_graph_destroy", "rwr_graph_size", "rwr_graph_get_normalized",
+    "rwr_graph_create", "rwr_graph_update_links", "rwr_graph_destroy", "rwr_graph_size", "rwr_graph_get_normalized",
     "rwr_recommend", "rwr_recommend_eval", "rwr_recommend_batch", "rwr_model_run",
     "rwr_part_begin", "rwr_part_local_step", "rwr_part_finish_step", "rwr_part_rank",
     "rwr_get_stats", "rwr_reset_stats",
@@ -65,6 +65,8 @@ def load():
     lib.rwr_graph_create.restype = C.c_int32
     lib.rwr_graph_create.argtypes = [C.c_int32, p(C.c_int64), p(C.c_uint8), p(C.c_int64), p(C.c_int32),
                                      p(C.c_uint8), p(C.c_double), p(rwr_opts), p(C.c_void_p)]
+    lib.rwr_graph_update_links.restype = C.c_int32
+    lib.rwr_graph_update_links.argtypes = [C.c_void_p, C.c_int64, p(C.c_int64), p(C.c_uint8), p(C.c_double)]
     lib.rwr_graph_destroy.restype = C.c_int32
     lib.rwr_graph_destroy.argtypes = [C.c_void_p]
     lib.rwr_graph_size.restype = C.c_int32

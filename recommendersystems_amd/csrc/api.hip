@@ -146,6 +146,19 @@ int32_t rwr_graph_create(int32_t n, const int64_t *node_id, const uint8_t *node_
     return RWR_OK;
 }
 
+int32_t rwr_graph_update_links(rwr_graph *g, int64_t count, const int64_t *link_index, const uint8_t *etype,
+                               const double *w)
+{
+    g_err[0] = 0;
+    if (!g) { set_error("rwr_graph_update_links: graph is NULL"); return RWR_E_INVALID; }
+    if (count < 0 || (count > 0 && !link_index)) {
+        set_error("rwr_graph_update_links: count must be >= 0 and link_index non-NULL when count > 0");
+        return RWR_E_INVALID;
+    }
+    if (hipSetDevice(g->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", g->device); return RWR_E_HIP; }
+    return graph_update_links(g, count, link_index, etype, w);
+}
+
 int32_t rwr_graph_destroy(rwr_graph *g)
 {
     if (!g) return RWR_OK;

@@ -112,6 +112,18 @@ __global__ void k_u32_to_i32(const uint32_t *__restrict__ a, int32_t *__restrict
     if (p < m) b[p] = (int32_t)a[p];
 }
 
+// incremental rebuild: overwrite type and/or weight of the listed raw links
+__global__ __launch_bounds__(256) void k_patch_links(int64_t count, const int64_t *__restrict__ idx,
+                                                     const uint8_t *__restrict__ new_type, const double *__restrict__ new_w,
+                                                     uint8_t *__restrict__ etype, double *__restrict__ w)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count) return;
+    const int64_t p = idx[q];
+    if (new_type) etype[p] = new_type[q];
+    if (new_w) w[p] = new_w[q];
+}
+
 static int bit_length(uint64_t v)
 {
     int b = 0;
@@ -119,6 +131,10 @@ static int bit_length(uint64_t v)
     return b;
 }
 
+static int32_t graph_derive(rwr_graph *g, bool first);
+
+// uploads the RAW lists (they stay resident: the exclusion list reads them, Recommender.cs:20-24, and an incremental
+// rebuild re-derives everything else from them), then derives the walk's data
 int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_type, const int64_t *rowptr,
                     const int32_t *dst, const uint8_t *etype, const double *w)
 {
@@ -139,6 +155,7 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     RWR_TRY(g->rowptr.alloc((size_t)n + 1));
     RWR_TRY(g->dst.alloc(m));
     RWR_TRY(g->etype.alloc(m));
+    RWR_TRY(g->w_raw.alloc(m));
     RWR_TRY(g->w_norm_raw.alloc(m));
     RWR_TRY(g->dangling.alloc(n));
     RWR_TRY(g->w_src.alloc(n));
@@ -147,12 +164,64 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     RWR_TRY(g->item_order.alloc(n_items));
     RWR_TRY(g->item_rows.alloc(n_items));
 
-    DevBuf<double> w_raw;
+    RWR_HIP(hipMemcpyAsync(g->node_id.p, node_id, sizeof(int64_t) * n, hipMemcpyHostToDevice, s));
+    RWR_HIP(hipMemcpyAsync(g->node_type.p, node_type, (size_t)n, hipMemcpyHostToDevice, s));
+    RWR_HIP(hipMemcpyAsync(g->rowptr.p, rowptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
+    if (m > 0) {
+        RWR_HIP(hipMemcpyAsync(g->dst.p, dst, sizeof(int32_t) * m, hipMemcpyHostToDevice, s));
+        RWR_HIP(hipMemcpyAsync(g->etype.p, etype, (size_t)m, hipMemcpyHostToDevice, s));
+        RWR_HIP(hipMemcpyAsync(g->w_raw.p, w, sizeof(double) * m, hipMemcpyHostToDevice, s));
+    }
+    return graph_derive(g, true);
+}
+
+// Incremental rebuild: patch type / weight of some raw links in place and re-derive.  The result is bit for bit
+// the state rwr_graph_create would build from the patched lists (same kernels, same order), without the host
+// re-sending the unchanged arrays: what the harness's per-fold / per-methodology rebuild (Experiment.cs:69-105)
+// reduces to when only link types (FRIENDSHIP -> UNDEFINED, Experiment.cs:84-101) or a few links change.
+int32_t graph_update_links(rwr_graph *g, int64_t count, const int64_t *idx, const uint8_t *etype, const double *w)
+{
+    hipStream_t s = g->stream;
+    if (count > 0) {
+        for (int64_t q = 0; q < count; ++q)
+            if (idx[q] < 0 || idx[q] >= g->nnz_raw) {
+                set_error("rwr_graph_update_links: link index %lld (entry %lld) is outside [0, %lld)", (long long)idx[q],
+                          (long long)q, (long long)g->nnz_raw);
+                return RWR_E_RANGE;
+            }
+        DevBuf<int64_t> d_idx;
+        DevBuf<uint8_t> d_t;
+        DevBuf<double> d_w;
+        RWR_TRY(d_idx.alloc((size_t)count));
+        RWR_HIP(hipMemcpyAsync(d_idx.p, idx, sizeof(int64_t) * count, hipMemcpyHostToDevice, s));
+        if (etype) {
+            RWR_TRY(d_t.alloc((size_t)count));
+            RWR_HIP(hipMemcpyAsync(d_t.p, etype, (size_t)count, hipMemcpyHostToDevice, s));
+        }
+        if (w) {
+            RWR_TRY(d_w.alloc((size_t)count));
+            RWR_HIP(hipMemcpyAsync(d_w.p, w, sizeof(double) * count, hipMemcpyHostToDevice, s));
+        }
+        hipLaunchKernelGGL(k_patch_links, dim3(cdiv((size_t)count, 256)), dim3(256), 0, s, count, d_idx.p,
+                           etype ? d_t.p : (const uint8_t *)nullptr, w ? d_w.p : (const double *)nullptr, g->etype.p,
+                           g->w_raw.p);
+        RWR_HIP(hipGetLastError());
+        RWR_HIP(hipStreamSynchronize(s));   // the staging buffers are released on return
+    }
+    return graph_derive(g, false);
+}
+
+// Graph.buildGraph + transpose + processing orders, from the device-resident raw lists
+static int32_t graph_derive(rwr_graph *g, bool first)
+{
+    const int32_t n = g->n;
+    const int64_t m = g->nnz_raw;
+    const int32_t n_items = g->n_items;
+    hipStream_t s = g->stream;
     DevBuf<int32_t> esrc;
     DevBuf<uint32_t> skey, skey2, sval, sval2;
     DevBuf<uint8_t> temp;
     DevBuf<int> flags;
-    RWR_TRY(w_raw.alloc(m));
     RWR_TRY(esrc.alloc(m));
     RWR_TRY(skey.alloc(m));
     RWR_TRY(skey2.alloc(m));
@@ -162,15 +231,6 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     size_t tbytes = radix_sort_temp_bytes((size_t)m, 1);
     size_t tb2 = radix_sort_temp_bytes((size_t)n, 1);
     RWR_TRY(temp.alloc(tbytes > tb2 ? tbytes : tb2));
-
-    RWR_HIP(hipMemcpyAsync(g->node_id.p, node_id, sizeof(int64_t) * n, hipMemcpyHostToDevice, s));
-    RWR_HIP(hipMemcpyAsync(g->node_type.p, node_type, (size_t)n, hipMemcpyHostToDevice, s));
-    RWR_HIP(hipMemcpyAsync(g->rowptr.p, rowptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
-    if (m > 0) {
-        RWR_HIP(hipMemcpyAsync(g->dst.p, dst, sizeof(int32_t) * m, hipMemcpyHostToDevice, s));
-        RWR_HIP(hipMemcpyAsync(g->etype.p, etype, (size_t)m, hipMemcpyHostToDevice, s));
-        RWR_HIP(hipMemcpyAsync(w_raw.p, w, sizeof(double) * m, hipMemcpyHostToDevice, s));
-    }
     int h_flags[4] = {0, 0, 0, 0};   // [0] some row non-uniform, [1] bad target, [2] max in-degree
     RWR_HIP(hipMemsetAsync(flags.p, 0, sizeof(h_flags), s));
 
@@ -178,7 +238,7 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     RWR_HIP(hipEventRecord(e0, s));
 
     hipLaunchKernelGGL(k_row_prepare, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->rowptr.p, g->dst.p, g->etype.p,
-                       w_raw.p, g->w_norm_raw.p, esrc.p, skey.p, sval.p, g->dangling.p, g->w_src.p, flags.p);
+                       g->w_raw.p, g->w_norm_raw.p, esrc.p, skey.p, sval.p, g->dangling.p, g->w_src.p, flags.p);
     RWR_HIP(hipGetLastError());
 
     // stable sort of the raw links by target (UNDEFINED links carry the sentinel key n and go last)
@@ -199,8 +259,8 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     }
     g->nnz = nnz;
     g->uniform = h_flags[0] ? 0 : 1;
-    RWR_TRY(g->in_src.alloc((size_t)nnz));
-    RWR_TRY(g->in_w.alloc((size_t)nnz));
+    RWR_TRY(g->in_src.ensure((size_t)nnz));
+    RWR_TRY(g->in_w.ensure((size_t)nnz));
     if (nnz > 0) {
         hipLaunchKernelGGL(k_gather_in, dim3(cdiv((size_t)nnz, 256)), dim3(256), 0, s, v_sorted, nnz, esrc.p,
                            g->w_norm_raw.p, g->in_src.p, g->in_w.p);
@@ -222,16 +282,18 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, 32, temp.p, s, &alt));
     hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p, g->row_order.p,
                        (int64_t)n);
-    // ITEM rows in ascending row order: one stable pass on the flag (item ? 0 : 1)
-    hipLaunchKernelGGL(k_item_flag_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->node_type.p, skey.p, sval.p);
-    RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, 8, temp.p, s, &alt));
-    if (n_items > 0)
-        hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n_items, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p,
-                           g->item_rows.p, (int64_t)n_items);
-    RWR_TRY(radix_sort_pairs<uint64_t>(ikey.p, ikey2.p, ival.p, ival2.p, (size_t)n, 1, 64, temp.p, s, &alt));
-    if (n_items > 0)
-        hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n_items, 256)), dim3(256), 0, s, alt ? ival2.p : ival.p,
-                           g->item_order.p, (int64_t)n_items);
+    if (first) {   // (the node arrays never change: an incremental rebuild keeps both item orders)
+        // ITEM rows in ascending row order: one stable pass on the flag (item ? 0 : 1)
+        hipLaunchKernelGGL(k_item_flag_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->node_type.p, skey.p, sval.p);
+        RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, 8, temp.p, s, &alt));
+        if (n_items > 0)
+            hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n_items, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p,
+                               g->item_rows.p, (int64_t)n_items);
+        RWR_TRY(radix_sort_pairs<uint64_t>(ikey.p, ikey2.p, ival.p, ival2.p, (size_t)n, 1, 64, temp.p, s, &alt));
+        if (n_items > 0)
+            hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n_items, 256)), dim3(256), 0, s, alt ? ival2.p : ival.p,
+                               g->item_order.p, (int64_t)n_items);
+    }
     RWR_HIP(hipGetLastError());
     RWR_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
     RWR_HIP(hipEventRecord(e1, s));
@@ -252,6 +314,8 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     float ms = 0.f;
     RWR_HIP(hipEventElapsedTime(&ms, e0, e1));
     g->stats.build_ms = ms;
+    g->stats.nnz = g->nnz;
+    g->stats.uniform = g->uniform;
     return RWR_OK;
 }
 

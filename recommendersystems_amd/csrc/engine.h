@@ -23,6 +23,7 @@ struct rwr_graph {
     rwr::DevBuf<int64_t> rowptr;
     rwr::DevBuf<int32_t> dst;
     rwr::DevBuf<uint8_t> etype;
+    rwr::DevBuf<double> w_raw;        // raw weights as handed over (kept for incremental rebuilds)
     rwr::DevBuf<double> w_norm_raw;   // Graph.graph weights per raw link (0 for UNDEFINED)
     std::vector<int64_t> h_rowptr;    // host copy (seed validation, exclusion sizing)
     std::vector<uint8_t> h_dangling;  // host copy of dangling[] (dangling seeds are answered without iterating)
@@ -77,6 +78,8 @@ namespace rwr {
 
 int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_type, const int64_t *rowptr,
                     const int32_t *dst, const uint8_t *etype, const double *w);
+
+int32_t graph_update_links(rwr_graph *g, int64_t count, const int64_t *idx, const uint8_t *etype, const double *w);
 
 // runs the power iteration for K seeds and leaves, per seed, the ranked list
 // (mode 0: top-k into host arrays; mode 1: full rank vector of one seed)

@@ -84,6 +84,7 @@ class Graph:
                                    tile_seeds, tile_group, 1 if profile else 0, workspace_bytes,
                                    {None: 0, "auto": 0, "fold": 1, "scan": 2, "simple": 3}[seed_row_kernel], 0)
         self._flat = None
+        self._sent = None
 
     # -- flat constructors (the layout of include/rwr.h), used by the bench for big graphs
     @classmethod
@@ -120,18 +121,44 @@ class Graph:
         return node_id, node_type, rowptr, dst, etype, w
 
     def buildGraph(self) -> None:
-        """Graph.buildGraph (Graph.cs:51-88) -> rwr_graph_create."""
+        """Graph.buildGraph (Graph.cs:51-88) -> rwr_graph_create.
+
+        Called again on the same object after the caller mutated its dictionaries (the harness relabels link types
+        between runs, Experiment.cs:84-101): when nodes, list lengths and targets are unchanged, only the links whose
+        type or weight differ are sent (rwr_graph_update_links); the device state is the same either way."""
         lib = _lib.load()
+        flat = self._flat if self._flat is not None else self._flatten()
+        node_id, node_type, rowptr, dst, etype, w = flat
+        if self._h and self._flat is None and self._sent is not None:
+            o_id, o_type, o_rowptr, o_dst, o_etype, o_w = self._sent
+            if (o_rowptr.shape == rowptr.shape and (o_rowptr == rowptr).all() and (o_dst == dst).all()
+                    and (o_id == node_id).all() and (o_type == node_type).all()):
+                changed = np.flatnonzero((o_etype != etype) | (o_w.view(np.uint64) != w.view(np.uint64))).astype(np.int64)
+                self.updateLinks(changed, etype[changed], w[changed])
+                self._sent = flat
+                return
         if self._h:
             lib.rwr_graph_destroy(self._h)
             self._h = C.c_void_p()
-        flat = self._flat if self._flat is not None else self._flatten()
-        node_id, node_type, rowptr, dst, etype, w = flat
         self._n = int(node_id.shape[0])
         self._rowptr = rowptr
         _lib.check(lib.rwr_graph_create(self._n, _p(node_id, C.c_int64), _p(node_type, C.c_uint8),
                                         _p(rowptr, C.c_int64), _p(dst, C.c_int32), _p(etype, C.c_uint8),
                                         _p(w, C.c_double), C.byref(self._opts), C.byref(self._h)))
+        self._sent = flat if self._flat is None else None     # (dictionary graphs: fresh arrays, kept for the next diff)
+        self._graph_cache = None
+
+    def updateLinks(self, link_index, etype=None, w=None) -> None:
+        """rwr_graph_update_links: new type / raw weight for the raw links at the given flattened positions, then the
+        device-side rebuild.  (Flat graphs: the caller's arrays are not touched; keep them in step yourself.)"""
+        idx = np.ascontiguousarray(link_index, dtype=np.int64)
+        et = None if etype is None else np.ascontiguousarray(etype, dtype=np.uint8)
+        ww = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+        if (et is not None and et.shape != idx.shape) or (ww is not None and ww.shape != idx.shape):
+            raise ValueError("etype / w must have one entry per link index")
+        _lib.check(_lib.load().rwr_graph_update_links(
+            self._handle(), int(idx.shape[0]), _p(idx, C.c_int64),
+            None if et is None else _p(et, C.c_uint8), None if ww is None else _p(ww, C.c_double)))
         self._graph_cache = None
 
     def size(self) -> int:

@@ -55,6 +55,8 @@ def test_argument_validation_without_gpu():
         assert st == L.RWR_E_NO_DEVICE            # fails loudly: there is no CPU fallback
         assert not out.value
     assert lib.rwr_graph_destroy(None) == L.RWR_OK
+    assert lib.rwr_graph_update_links(None, 0, None, None, None) == L.RWR_E_INVALID
+    assert b"graph is NULL" in lib.rwr_last_error()
 
 
 def test_product_package_never_touches_the_oracle():

@@ -540,3 +540,93 @@ def test_hub_nodes_long_rows(amd, mode):
     si, ss = F.recommend(1234, 0.15, 10, 50)
     assert [r[0] for r in single] == si.tolist() and len(si) == 50
     assert np.abs(np.array([r[1] for r in single]) - ss).max() <= (0 if mode == "exact" else 1e-6)
+
+
+def _same_results(amd, G, F, seeds, T=6, top_n=15):
+    ids, sc, cnt = amd.Recommender(G).RecommendationBatch(seeds, 0.15, T, top_n)
+    oi, os_, oc = F.recommend_batch(seeds, 0.15, T, top_n)
+    assert (cnt == oc).all() and (ids == oi).all() and (bits(sc) == bits(os_)).all()
+    wn, dg = G.normalized()
+    assert (bits(wn) == bits(F.w_norm)).all() and (dg == F.dangling).all()
+    full = amd.Recommender(G).Recommendation(int(seeds[0]), 0.15, T)
+    fi, fs = F.recommend(int(seeds[0]), 0.15, T)
+    assert [r[0] for r in full] == fi.tolist() and (bits([r[1] for r in full]) == bits(fs)).all()
+
+
+def test_incremental_rebuild_matches_fresh_build(amd):
+    """rwr_graph_update_links: relabel FRIENDSHIP -> UNDEFINED as Experiment.cs:84-101 does, change raw
+    weights, make a node dangling, revert -- after every patch the device state must equal a graph built from scratch
+    from the patched lists (checked against the oracle on those lists), without re-sending the unchanged arrays."""
+    g = gg.random_graph(77, n_users=400, n_items=1200, n_likes=7000, n_etc=10, n_friend=900, n_mention=300, n_author=200)
+    seeds = np.array([0, 3, 50, 399, 120], dtype=np.int32)
+    G = dev_graph(amd, g, profile=True)
+    _same_results(amd, G, FlatGraph(**g), seeds)
+    handle = G._h.value
+    # 1. the harness's relabel: every FRIENDSHIP link becomes UNDEFINED
+    et = g["etype"].copy()
+    fr = np.flatnonzero(et == gg.EDGE_FRIENDSHIP)
+    assert len(fr) > 100
+    et[fr] = gg.EDGE_UNDEFINED
+    G.updateLinks(fr, etype=et[fr])
+    g1 = dict(g, etype=et)
+    _same_results(amd, G, FlatGraph(**g1), seeds)
+    assert G.stats()["nnz"] == int((et != 0).sum()) and G._h.value == handle
+    # 2. weights only (MENTION-like), types untouched
+    w = g["w"].copy()
+    mi = np.flatnonzero(et == gg.EDGE_MENTION)[::2]
+    w[mi] = w[mi] * 3.0 + 0.125
+    G.updateLinks(mi, w=w[mi])
+    g2 = dict(g1, w=w)
+    _same_results(amd, G, FlatGraph(**g2), seeds)
+    # 3. types and weights together; node 3 loses every link (becomes dangling), a LIKE of seed 0 becomes PURCHASE
+    et3 = et.copy(); w3 = w.copy()
+    r3 = np.arange(g["rowptr"][3], g["rowptr"][4])
+    et3[r3] = gg.EDGE_UNDEFINED
+    l0 = np.flatnonzero(et3[g["rowptr"][0]:g["rowptr"][1]] == gg.EDGE_LIKE)[:1] + g["rowptr"][0]
+    et3[l0] = gg.EDGE_PURCHASE; w3[l0] = 2.5
+    idx = np.concatenate([r3, l0])
+    G.updateLinks(idx, etype=et3[idx], w=w3[idx])
+    g3 = dict(g2, etype=et3, w=w3)
+    _same_results(amd, G, FlatGraph(**g3), seeds)
+    # 4. back to the original lists: same results as the very first build
+    diff = np.flatnonzero((et3 != g["etype"]) | (w3 != g["w"]))
+    G.updateLinks(diff, etype=g["etype"][diff], w=g["w"][diff])
+    _same_results(amd, G, FlatGraph(**g), seeds)
+    # errors leave the graph usable
+    with pytest.raises(amd.RwrError) as ei:
+        G.updateLinks(np.array([len(et)], dtype=np.int64), etype=np.array([1], dtype=np.uint8))
+    assert ei.value.status == 2                                   # RWR_E_RANGE
+    G.updateLinks(np.zeros(0, dtype=np.int64))                     # count 0: plain rebuild
+    _same_results(amd, G, FlatGraph(**g), seeds)
+    G.close()
+
+
+def test_rebuild_of_mutated_dictionaries_sends_only_the_diff(amd):
+    """The reference-shaped classes: the host mutates ForwardLink.type in place (Experiment.cs:90-97) and calls
+    buildGraph() again; the mirror sends only the changed links (same native handle) and the results equal the oracle's
+    on the mutated containers."""
+    g = gg.random_graph(31, n_users=60, n_items=200, n_likes=900, n_friend=150, n_mention=40)
+    nodes = {i: amd.Node(int(g["node_id"][i]), amd.NodeType(int(g["node_type"][i]))) for i in range(len(g["node_id"]))}
+    edges = {i: [amd.ForwardLink(int(g["dst"][e]), amd.EdgeType(int(g["etype"][e])), float(g["w"][e]))
+                 for e in range(g["rowptr"][i], g["rowptr"][i + 1])] for i in range(len(nodes))}
+    graph = amd.Graph(nodes, edges)
+    graph.buildGraph()
+    handle = graph._h.value
+    before = amd.Recommender(graph).Recommendation(0, 0.15, 8)
+    for i in edges:                                               # Experiment.cs:84-101
+        for l in edges[i]:
+            if l.type == amd.EdgeType.FRIENDSHIP:
+                l.type = amd.EdgeType.UNDEFINED
+    graph.buildGraph()
+    assert graph._h.value == handle
+    after = amd.Recommender(graph).Recommendation(0, 0.15, 8)
+    pn, pe = po.from_flat(g["node_id"], g["node_type"], g["rowptr"], g["dst"],
+                          np.where(g["etype"] == gg.EDGE_FRIENDSHIP, 0, g["etype"]).astype(np.uint8), g["w"])
+    PG = po.Graph(pn, pe); PG.buildGraph()
+    ref = po.Recommender(PG).Recommendation(0, 0.15, 8)
+    assert [r[0] for r in after] == [r[0] for r in ref] and (bits([r[1] for r in after]) == bits([r[1] for r in ref])).all()
+    assert after != before
+    # a structural change (one more link) falls back to a full re-create
+    edges[1].append(amd.ForwardLink(5, amd.EdgeType.FOLLOW, 1.0))
+    graph.buildGraph()
+    assert len(graph.graph[1]) == sum(1 for l in edges[1] if l.type != amd.EdgeType.UNDEFINED)
