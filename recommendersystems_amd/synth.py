@@ -19,6 +19,8 @@ CONFIGS = {
     "C2": (2, 100_000, 500_000, 10_000_000, 1000),
     "C3": (3, 162_000, 62_000, 25_000_000, 8192),
     "C4": (4, 1_000_000, 5_000_000, 100_000_000, 1024),
+    # config 5's graph (row-partitioned over 8 GPUs in BASELINE.md); its 2 G links also fit ONE MI355X (about 110 GB during the build)
+    "C5": (5, 10_000_000, 50_000_000, 1_000_000_000, 8),
 }
 
 
