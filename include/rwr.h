@@ -166,6 +166,9 @@ int32_t rwr_graph_get_normalized(rwr_graph *g, double *w_out /* nnz_raw */, uint
  *   (:27-31), sorted by score desc then id desc (:35-38).
  * d crosses as float and is widened natively, as Recommender.cs:16 -> Model.cs:33 does.
  * top_n <= 0 returns the whole list (the reference's Count == topN test never fires).
+ * Domain: raw weights >= 0 with a positive finite sum per node (what the reference's loader
+ * produces); on a graph with a negative / NaN weight or a zero row sum the Recommendation
+ * entries fail with RWR_E_UNSUPPORTED (rwr_model_run still reproduces the reference there).
  * in:  *inout_count = capacity of out_id/out_score;  out: entries written.  If the list
  * needs more room the call fails with RWR_E_CAPACITY and *inout_count = required size
  * (n always suffices). */

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_row_prepare(
     int64_t b = rowptr[i], e = rowptr[i + 1];
     double sum = 0.0;
     int64_t n_explicit = 0;
-    bool uni = true, bad = false;
+    bool uni = true, bad = false, neg = false;
     double first = 0.0;
     for (int64_t p = b; p < e; ++p) {
         int32_t t = dst[p];
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void k_row_prepare(
             else if (wp != first) uni = false;
             sum += wp;                                   // Graph.cs:75, list order
             ++n_explicit;
+            if (!(wp >= 0.0)) neg = true;                // negative or NaN raw weight
         }
     }
     for (int64_t p = b; p < e; ++p) {
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void k_row_prepare(
     w_src[i] = (n_explicit > 0) ? first / sum : 0.0;
     if (!uni) atomicOr(&flags[0], 1);
     if (bad) atomicOr(&flags[1], 1);
+    if (neg || (n_explicit > 0 && !(sum > 0.0 && sum < __longlong_as_double(0x7ff0000000000000ll)))) atomicOr(&flags[3], 1);
 }
 
 // in_ptr[j] = first sorted position whose key >= j   (keys sorted ascending, sentinel n last)
@@ -231,7 +233,7 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     size_t tbytes = radix_sort_temp_bytes((size_t)m, 1);
     size_t tb2 = radix_sort_temp_bytes((size_t)n, 1);
     RWR_TRY(temp.alloc(tbytes > tb2 ? tbytes : tb2));
-    int h_flags[4] = {0, 0, 0, 0};   // [0] some row non-uniform, [1] bad target, [2] max in-degree
+    int h_flags[4] = {0, 0, 0, 0};   // [0] some row non-uniform, [1] bad target, [2] max in-degree, [3] a weight or row sum not in (0, inf)
     RWR_HIP(hipMemsetAsync(flags.p, 0, sizeof(h_flags), s));
 
     hipEvent_t e0 = g->ev_a, e1 = g->ev_b;
@@ -259,6 +261,7 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     }
     g->nnz = nnz;
     g->uniform = h_flags[0] ? 0 : 1;
+    g->nonneg = h_flags[3] ? 0 : 1;
     RWR_TRY(g->in_src.ensure((size_t)nnz));
     RWR_TRY(g->in_w.ensure((size_t)nnz));
     if (nnz > 0) {

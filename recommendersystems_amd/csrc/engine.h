@@ -9,6 +9,8 @@ struct rwr_graph {
     int64_t nnz = 0;         // explicit links = entries of the transition matrix
     int32_t n_items = 0;     // nodes of type ITEM
     int32_t uniform = 0;     // every row's explicit raw weights equal
+    int32_t nonneg = 1;      // every normalised weight is a finite number >= 0 (raw weights >= 0, row sums in (0, inf)): ranks stay
+                             // >= 0, which the zero-skipping frontier paths and the binade scan rely on; otherwise the general kernels run
     int32_t max_in_deg = 0;
     // rows of row_order (in-degree descending) with in-degree >= 128 / >= 32 / >= 4: lane-width bins of the K = 1 vector SpMV
     int32_t bin_end[3] = {0, 0, 0};

@@ -864,7 +864,8 @@ struct GroupIter {
         // frontier bitmaps for the first iterations (chunked SpMM only)
         static const int nz_iters_env = [] { const char *e = getenv("RWR_NZ_ITERS"); return e ? atoi(e) : 4; }();
         static const int spmm_variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
-        nz_iters = (G >= 8 && spmm_variant != 0) ? nz_iters_env : 0;
+        // (skipping +0.0 addends is only a bitwise no-op while every accumulator is >= +0.0: weights must be >= 0)
+        nz_iters = (G >= 8 && spmm_variant != 0 && g->nonneg) ? nz_iters_env : 0;
         const size_t nzw = ((size_t)n + 31) / 32;
         nz_cur = nz_iters > 0 ? g->d_nz.p : nullptr;
         nz_oth = nz_iters > 0 ? g->d_nz.p + (size_t)tg * nzw : nullptr;
@@ -885,7 +886,7 @@ struct GroupIter {
         const int sel = g->opts.seed_row_kernel;
         chain_kind = sel == 1 ? 3 : sel == 2 ? 2 : sel == 3 ? 0 : chain_env;
         const double per_seed = 0.89 * (double)g->nnz / (double)(g->n > 0 ? g->n : 1) + 6.7;
-        scan = g->opts.mode != RWR_MODE_FAST && c1 >= 0.0 && c1 <= 1.0 &&
+        scan = g->opts.mode != RWR_MODE_FAST && c1 >= 0.0 && c1 <= 1.0 && g->nonneg &&
                (chain_kind == 2 || (chain_kind == 1 && (double)tg * G * per_seed < scan_work));
         if (scan) RWR_TRY(chain_scan_prepare(g, G, tg, d_seeds, s));
         return RWR_OK;
@@ -1063,6 +1064,13 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
 {
     const double t_begin = now_ms();
     const int32_t n = g->n;
+    if (!g->nonneg) {
+        // the exclusion marker (-1) and the ranking keys assume scores >= 0, i.e. weights >= 0 and finite row sums -- what
+        // the reference's loader produces (DataLoader.cs:293-294,431-432).  Model.run still works on such a graph.
+        set_error("Recommendation needs non-negative finite link weights and positive row sums (a raw weight is negative or "
+                  "NaN, or the explicit weights of a node sum to 0 or overflow); rwr_model_run accepts such graphs");
+        return RWR_E_UNSUPPORTED;
+    }
     for (int32_t k = 0; k < K; ++k)
         if (seeds[k] < 0 || seeds[k] >= n) {
             set_error("seed %d (batch position %d) is outside [0, %d)", seeds[k], k, n);

@@ -630,3 +630,30 @@ def test_rebuild_of_mutated_dictionaries_sends_only_the_diff(amd):
     edges[1].append(amd.ForwardLink(5, amd.EdgeType.FOLLOW, 1.0))
     graph.buildGraph()
     assert len(graph.graph[1]) == sum(1 for l in edges[1] if l.type != amd.EdgeType.UNDEFINED)
+
+
+def test_negative_weights_take_the_general_path(amd):
+    """Raw weights < 0 are outside the loader's domain (DataLoader.cs:293-294,431-432) but the containers allow them: ranks
+    can then go negative, so the zero-skipping frontier kernels and the binade scan (both rely on ranks >= 0) step aside;
+    Model.run stays bitwise equal to the literal restatement, Recommendation refuses loudly."""
+    g = gg.random_graph(5, n_users=50, n_items=120, n_likes=700, n_friend=60, n_mention=50)
+    w = g["w"].copy()
+    rng = np.random.default_rng(3)
+    pick = rng.choice(len(w), 40, replace=False)
+    w[pick] = -0.25 * w[pick]                               # row sums stay non-zero (weights are >= 0.3 in magnitude mix)
+    g2 = dict(g, w=w)
+    nodes, edges = po.from_flat(g2["node_id"], g2["node_type"], g2["rowptr"], g2["dst"], g2["etype"], g2["w"])
+    PG = po.Graph(nodes, edges)
+    PG.buildGraph()
+    for tile_seeds in (0, 16):
+        G = dev_graph(amd, g2, tile_seeds=tile_seeds)
+        for seed in (0, 7):
+            m = po.Model(PG, po.widen_float(0.15), seed, dense_restart=True)
+            m.run(6)
+            dm = amd.Model(G, po.widen_float(0.15), seed)
+            dm.run(6)
+            assert (bits(dm.rank) == bits(m.rank)).all()
+        with pytest.raises(amd.RwrError) as ei:
+            amd.Recommender(G).Recommendation(0, 0.15, 5)
+        assert ei.value.status == 7 and "non-negative" in str(ei.value)
+        G.close()
