@@ -81,6 +81,58 @@ __global__ __launch_bounds__(256) void k_spmm(int32_t n, const int64_t *__restri
     }
 }
 
+// K = 1, EXACT mode: one lane per destination row, the row's in-list walked sequentially in the reference's addend
+// order (bitwise).  Rows come in in-degree order, so the lanes of a wave have lists of similar length.  Each lane
+// streams ITS list with wide loads -- 8 indices as two 16-byte loads, 8 weights as four -- so a fetched 64-byte
+// sector is consumed whole by the lane that fetched it (per-entry 4- and 8-byte loads would move one sector per
+// entry through the L1), and keeps the 8 gathers of x in flight before the first dependent add.
+typedef int v4i_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
+__global__ __launch_bounds__(256) void k_spmv_exact(int32_t n, const int64_t *__restrict__ in_ptr,
+                                                    const int32_t *__restrict__ in_src,
+                                                    const double *__restrict__ in_w,
+                                                    const int32_t *__restrict__ row_order,
+                                                    const double *__restrict__ x, double *__restrict__ y,
+                                                    const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
+                                                    const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
+{
+    const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const int32_t j = row_order[r];
+        int64_t p = in_ptr[j];
+        int64_t e = in_ptr[j + 1];
+        // first iterations: a row none of whose in-neighbours holds a non-zero (k_mark_active) stays exactly +0.0
+        if (act && !((act[(uint32_t)j >> 5] >> (j & 31)) & 1u)) e = p;
+        double acc = 0.0;
+        for (; p + 8 <= e; p += 8) {
+            const v4i_u i0 = *reinterpret_cast<const v4i_u *>(in_src + p);
+            const v4i_u i1 = *reinterpret_cast<const v4i_u *>(in_src + p + 4);
+            const v2d_u w0 = *reinterpret_cast<const v2d_u *>(in_w + p);
+            const v2d_u w1 = *reinterpret_cast<const v2d_u *>(in_w + p + 2);
+            const v2d_u w2 = *reinterpret_cast<const v2d_u *>(in_w + p + 4);
+            const v2d_u w3 = *reinterpret_cast<const v2d_u *>(in_w + p + 6);
+            const double x0 = x[i0.x], x1 = x[i0.y], x2 = x[i0.z], x3 = x[i0.w];
+            const double x4 = x[i1.x], x5 = x[i1.y], x6 = x[i1.z], x7 = x[i1.w];
+            double rw;
+            rw = c1 * x0; acc += rw * w0.x;      // Model.cs:84,87 -- in list order
+            rw = c1 * x1; acc += rw * w0.y;
+            rw = c1 * x2; acc += rw * w1.x;
+            rw = c1 * x3; acc += rw * w1.y;
+            rw = c1 * x4; acc += rw * w2.x;
+            rw = c1 * x5; acc += rw * w2.y;
+            rw = c1 * x6; acc += rw * w3.x;
+            rw = c1 * x7; acc += rw * w3.y;
+        }
+        for (; p < e; ++p) {
+            const double rw = c1 * x[in_src[p]];
+            acc += rw * in_w[p];
+        }
+        if (j != my_seed) y[j] = acc;
+        if (nz_out && acc != 0.0) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
+    }
+}
+
 // K = 1, FAST mode: the classic vector-CSR SpMV.  W lanes share one destination row: each lane streams every W-th
 // entry of the row's in-list (coalesced index and weight reads), gathers x, keeps a private partial sum, and the W
 // partials are combined with a shuffle butterfly whose shape depends only on W -- rows of equal structure get
@@ -712,6 +764,12 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
             launch_spmv_vector(g, X, Y, c1, s);
             return;
         }
+        if (tg == 1 && variant != 0) {
+            const unsigned blocks = cdiv((size_t)g->n, 256);
+            hipLaunchKernelGGL(k_spmv_exact, dim3(blocks < 16384u ? blocks : 16384u), dim3(256), 0, s, g->n, g->in_ptr.p,
+                               g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, act, nz_out);
+            return;
+        }
     }
     if constexpr (G >= 8) {
         if (variant != 0) {
@@ -850,6 +908,7 @@ struct GroupIter {
     int64_t it = 0;
     bool scan = false;   // exact mode: seed-row chain by the parallel binade scan (chain_scan.hip)
     int chain_kind = 1;  // 0 simple one-lane loop, 1 auto, 2 scan, 3 role-specialised fold
+    int act_iters = 0;   // iterations whose SpMM only visits the out-neighbours of non-zero rows
 
     GroupIter(rwr_graph *g_, int G_, int tg_, const int32_t *seeds, const int64_t *evoff, double d)
         : g(g_), G(G_), tg(tg_), d_seeds(seeds), d_evoff(evoff), c1(1 - d) /* Model.cs:84: (1 - dampingFactor) */,
@@ -866,6 +925,13 @@ struct GroupIter {
         static const int spmm_variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
         // (skipping +0.0 addends is only a bitwise no-op while every accumulator is >= +0.0: weights must be >= 0)
         nz_iters = (G >= 8 && spmm_variant != 0 && g->nonneg) ? nz_iters_env : 0;
+        // iterations 0 and 1: the non-zero rows are few enough to mark their out-neighbours; every other row is 0
+        // (iteration 1 only on sparse graphs: on dense ones -- hundreds of links per node -- marking the 2-hop
+        //  neighbourhood costs more atomics than the skipped rows save)
+        static const int act_env = [] { const char *e = getenv("RWR_ACT_ITERS"); return e ? atoi(e) : -1; }();
+        act_iters = act_env >= 0 ? act_env : ((g->nnz / (g->n > 0 ? g->n : 1)) <= 64 ? 2 : 1);
+        // single exact seed (lane-per-row SpMV): row-level skipping only, for exactly those iterations
+        if (G == 1 && tg == 1 && spmm_variant != 0 && g->nonneg && g->opts.mode != RWR_MODE_FAST) nz_iters = act_iters;
         const size_t nzw = ((size_t)n + 31) / 32;
         nz_cur = nz_iters > 0 ? g->d_nz.p : nullptr;
         nz_oth = nz_iters > 0 ? g->d_nz.p + (size_t)tg * nzw : nullptr;
@@ -906,11 +972,6 @@ struct GroupIter {
         const uint32_t *nz_in = (it < nz_iters) ? nz_cur : nullptr;
         uint32_t *nz_out = (it + 1 < nz_iters) ? nz_oth : nullptr;
         if (nz_out) RWR_HIP(hipMemsetAsync(nz_out, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
-        // iterations 0 and 1: the non-zero rows are few enough to mark their out-neighbours; every other row is 0
-        // (iteration 1 only on sparse graphs: on dense ones -- hundreds of links per node -- marking the 2-hop
-        //  neighbourhood costs more atomics than the skipped rows save)
-        static const int act_env = [] { const char *e = getenv("RWR_ACT_ITERS"); return e ? atoi(e) : -1; }();
-        const int act_iters = act_env >= 0 ? act_env : ((g->nnz / (g->n > 0 ? g->n : 1)) <= 64 ? 2 : 1);
         uint32_t *act = (nz_in && it < act_iters) ? g->d_nz.p + 2 * (size_t)tg * nzw : nullptr;
         if (act) {
             RWR_HIP(hipMemsetAsync(act, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
@@ -918,7 +979,8 @@ struct GroupIter {
                                g->dst.p, g->etype.p);
         }
         if (exact && serial) s2 = s;
-        const bool scan_now = exact && scan && !act;
+        // (while X is sparse the bitmap-walking chain serves a whole tile at once; for a single seed the scan is cheaper)
+        const bool scan_now = exact && scan && (!act || G == 1);
         if (scan_now) {
             // parallel chain on the main stream, ahead of the SpMM (which skips the seed rows)
             RWR_DISPATCH_G(G, launch_seed_terms<GG>(g, tg, X, d_seeds, c1, d_evoff, s));
