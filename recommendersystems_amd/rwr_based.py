@@ -271,9 +271,9 @@ class Recommender:
         if g.edges is not None and idxTargetUser not in g.edges:
             raise KeyError(idxTargetUser)        # graph.edges[idxTargetUser], Recommender.cs:21
         lib = _lib.load()
-        cap = g.size()
-        ids = np.zeros(max(cap, 1), dtype=np.int64)
-        sc = np.zeros(max(cap, 1), dtype=np.float64)
+        cap = g.size() if topN is None or topN <= 0 else min(g.size(), int(topN))
+        ids = np.empty(max(cap, 1), dtype=np.int64)
+        sc = np.empty(max(cap, 1), dtype=np.float64)
         cnt = C.c_int64(cap)
         _lib.check(lib.rwr_recommend(g._handle(), int(idxTargetUser), C.c_float(dampingFactor), int(nIteration),
                                      0 if topN is None else int(topN), _p(ids, C.c_int64), _p(sc, C.c_double),
