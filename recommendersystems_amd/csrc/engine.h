@@ -102,4 +102,5 @@ int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y,
                         const int64_t *d_evoff, double c1, uint32_t *nz_out, hipStream_t s);
 int32_t chain_scan_collect(rwr_graph *g, hipStream_t s);
 
+
 }  // namespace rwr

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_spmm(int32_t n, const int64_t *__restri
 // entry through the L1), and keeps the 8 gathers of x in flight before the first dependent add.
 typedef int v4i_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
-__global__ __launch_bounds__(256) void k_spmv_exact(int32_t n, const int64_t *__restrict__ in_ptr,
+__global__ __launch_bounds__(256) void k_spmv_exact(int32_t r0, int32_t n, const int64_t *__restrict__ in_ptr,
                                                     const int32_t *__restrict__ in_src,
                                                     const double *__restrict__ in_w,
                                                     const int32_t *__restrict__ row_order,
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_spmv_exact(int32_t n, const int64_t *__
 {
     const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+    for (int64_t r = (int64_t)r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
         const int32_t j = row_order[r];
         int64_t p = in_ptr[j];
         int64_t e = in_ptr[j + 1];
@@ -130,6 +130,120 @@ __global__ __launch_bounds__(256) void k_spmv_exact(int32_t n, const int64_t *__
         }
         if (j != my_seed) y[j] = acc;
         if (nz_out && acc != 0.0) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
+    }
+}
+
+// K = 1, EXACT mode, LONG rows (in-degree >= 128: hub items, the ego of an ego network): one lane walking such a list
+// alone pays a memory round trip per few entries and the longest row becomes the kernel's run time.  Here a whole wave
+// serves the row: 64 consecutive entries are loaded coalesced, their 64 gathers of x fly together and the products
+// rw * weight (Model.cs:84,87) are formed in parallel -- only the ADDS stay sequential, in list order, each taking
+// the next product from its lane (v_readlane) into the wave-uniform accumulator:  8 cycles per entry instead of a
+// memory latency, bit for bit the same sum.  The next 64 entries are fetched while the adds of the current ones run.
+__device__ __forceinline__ double readlane_f64(double v, int t)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), t);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), t);
+    return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(256) void k_spmv_exact_wave(int32_t r1, const int64_t *__restrict__ in_ptr,
+                                                         const int32_t *__restrict__ in_src,
+                                                         const double *__restrict__ in_w,
+                                                         const int32_t *__restrict__ row_order,
+                                                         const double *__restrict__ x, double *__restrict__ y,
+                                                         const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
+                                                         const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) / WAVE;
+    for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE; r < r1; r += nwaves) {
+        const int32_t j = row_order[r];
+        int64_t p = in_ptr[j];
+        int64_t e = in_ptr[j + 1];
+        if (act && !((act[(uint32_t)j >> 5] >> (j & 31)) & 1u)) e = p;
+        double acc = 0.0;
+        double cur = 0.0;
+        if (p + lane < e) {
+            const double rw = c1 * x[in_src[p + lane]];
+            cur = rw * in_w[p + lane];
+        }
+        while (p < e) {
+            const int64_t pn = p + WAVE;
+            double nxt = 0.0;
+            if (pn + lane < e) {                       // issued ahead of the dependent adds below
+                const double rw = c1 * x[in_src[pn + lane]];
+                nxt = rw * in_w[pn + lane];
+            }
+            if (e - p >= WAVE) {
+#pragma unroll
+                for (int t = 0; t < WAVE; ++t) acc += readlane_f64(cur, t);
+            } else {
+                const int cnt = (int)(e - p);
+                for (int t = 0; t < cnt; ++t) acc += __shfl(cur, t, WAVE);
+            }
+            cur = nxt;
+            p = pn;
+        }
+        if (lane == 0) {
+            if (j != my_seed) y[j] = acc;
+            if (nz_out && acc != 0.0) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
+        }
+    }
+}
+
+// The same idea for shorter rows: W (16 or 4) lanes share a row, 64 / W rows per wave.  The W products of a round are
+// formed in parallel; every lane of the group then adds them in list order (the group's lanes all carry the row's
+// accumulator), taking product t from lane t of its group.
+template <int W>
+__global__ __launch_bounds__(256) void k_spmv_exact_group(int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
+                                                          const int32_t *__restrict__ in_src,
+                                                          const double *__restrict__ in_w,
+                                                          const int32_t *__restrict__ row_order,
+                                                          const double *__restrict__ x, double *__restrict__ y,
+                                                          const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
+                                                          const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
+{
+    constexpr int RPW = WAVE / W;
+    const int lane = threadIdx.x & (WAVE - 1), gl = lane % W, grp = lane / W;
+    const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) / WAVE;
+    for (int64_t rb = (int64_t)r0 + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE) * RPW; rb < r1; rb += nwaves * RPW) {
+        const int64_t r = rb + grp;
+        int32_t j = -1;
+        int64_t p = 0, e = 0;
+        if (r < r1) {
+            j = row_order[r];
+            p = in_ptr[j];
+            e = in_ptr[j + 1];
+            if (act && !((act[(uint32_t)j >> 5] >> (j & 31)) & 1u)) e = p;
+        }
+        double acc = 0.0;
+        double cur = 0.0;
+        if (p + gl < e) {
+            const double rw = c1 * x[in_src[p + gl]];
+            cur = rw * in_w[p + gl];
+        }
+        while (__any(p < e)) {
+            const int64_t pn = p + W;
+            double nxt = 0.0;
+            if (pn + gl < e) {
+                const double rw = c1 * x[in_src[pn + gl]];
+                nxt = rw * in_w[pn + gl];
+            }
+            const int64_t left = e - p;
+            const int cnt = left > W ? W : (left > 0 ? (int)left : 0);
+#pragma unroll
+            for (int t = 0; t < W; ++t) {
+                const double v = __shfl(cur, t, W);
+                if (t < cnt) acc += v;
+            }
+            cur = nxt;
+            if (p < e) p = pn;
+        }
+        if (gl == 0 && j >= 0) {
+            if (j != my_seed) y[j] = acc;
+            if (nz_out && acc != 0.0) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
+        }
     }
 }
 
@@ -765,9 +879,30 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
             return;
         }
         if (tg == 1 && variant != 0) {
-            const unsigned blocks = cdiv((size_t)g->n, 256);
-            hipLaunchKernelGGL(k_spmv_exact, dim3(blocks < 16384u ? blocks : 16384u), dim3(256), 0, s, g->n, g->in_ptr.p,
-                               g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, act, nz_out);
+            // rows are in in-degree order (unless RWR_ROW_ORDER says otherwise): the first bin_end[0] have >= 128 in-links
+            static const bool by_degree = [] { const char *e = getenv("RWR_ROW_ORDER"); return !e || atoi(e) == 0; }();
+            // in-degree >= 128: a wave per row; >= 32: 16 lanes per row; >= 4: 4 lanes per row; below: a lane per row
+            // (RWR_GROUP_ROWS = 0 keeps everything under 128 on the lane-per-row kernel)
+            static const int group_rows = [] { const char *e = getenv("RWR_GROUP_ROWS"); return e ? atoi(e) : 2; }();
+            const int32_t b0 = by_degree ? g->bin_end[0] : 0;
+            const int32_t b1 = (by_degree && group_rows >= 1) ? g->bin_end[1] : b0;
+            const int32_t b2 = (by_degree && group_rows >= 2) ? g->bin_end[2] : b1;
+            const int32_t r_long = b2;
+            auto blocks_for = [](int64_t rows, int W) { const int64_t b = (rows * W + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); };
+            if (b0 > 0)
+                hipLaunchKernelGGL(k_spmv_exact_wave, dim3(blocks_for(b0, 64)), dim3(256), 0, s, b0, g->in_ptr.p,
+                                   g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, act, nz_out);
+            if (b1 > b0)
+                hipLaunchKernelGGL(k_spmv_exact_group<16>, dim3(blocks_for(b1 - b0, 16)), dim3(256), 0, s, b0, b1, g->in_ptr.p,
+                                   g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, act, nz_out);
+            if (b2 > b1)
+                hipLaunchKernelGGL(k_spmv_exact_group<4>, dim3(blocks_for(b2 - b1, 4)), dim3(256), 0, s, b1, b2, g->in_ptr.p,
+                                   g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, act, nz_out);
+            if (g->n > r_long) {
+                const unsigned blocks = cdiv((size_t)(g->n - r_long), 256);
+                hipLaunchKernelGGL(k_spmv_exact, dim3(blocks < 16384u ? blocks : 16384u), dim3(256), 0, s, r_long, g->n,
+                                   g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, act, nz_out);
+            }
             return;
         }
     }

@@ -97,3 +97,23 @@ def test_monotone_id_relabelling_keeps_scores(big):
     ids2, sc2, _ = amd.Recommender(G2).RecommendationBatch(seeds, 0.15, 10, 50)
     assert (ids2 == ids * 3 + 7).all() and (bits(sc) == bits(sc2)).all()
     G2.close()
+
+
+def test_seed_row_kernels_agree_at_full_size(big):
+    """The sequential fold and the parallel binade scan of the seed's own row are two implementations of the same
+    arithmetic: at full size their results must be identical bit for bit (and the scan must have carried most blocks
+    without redoing them)."""
+    amd, synth, g, flat, G = big
+    seeds = synth.seeds_for(g["users"], 40, 0, 40)
+    out = {}
+    for kern in ("fold", "scan"):
+        Gk = amd.Graph.from_flat(**flat, seed_row_kernel=kern, profile=True)
+        Gk.buildGraph()
+        out[kern] = amd.Recommender(Gk).RecommendationBatch(seeds, 0.15, 10, 100)
+        if kern == "scan":
+            n = g["users"] + g["items"]
+            blocks = -(-n * Gk.stats()["tile_seeds"] // 4096) * len(seeds) * 10
+            assert 0 < Gk.stats()["chain_redo_blocks"] < 0.1 * blocks
+        Gk.close()
+    assert (out["fold"][0] == out["scan"][0]).all() and (bits(out["fold"][1]) == bits(out["scan"][1])).all()
+    assert (out["fold"][2] == out["scan"][2]).all()
