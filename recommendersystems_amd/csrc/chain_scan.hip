@@ -34,8 +34,13 @@
 
 namespace rwr {
 
-constexpr int CS_E = 4096;    // rank-matrix elements per block (rows x G)
-constexpr int CS_R = 16;      // rows per thread run
+// rank-matrix elements per block (rows x G).  A single seed gets 1024-row blocks: a block that crosses a binade is
+// redone row by row by ONE wave, and that serial redo, not the parallel passes, is what a single-seed step waits for.
+template <int G> struct CsGeom {
+    static constexpr int E = (G == 1) ? 1024 : 4096;
+    static constexpr int R = E / 256;          // rows per thread run of k_cs_block
+    static constexpr int CH = E / G;           // rows per block
+};
 constexpr unsigned long long CS_HID = 1ull << 52;
 constexpr unsigned long long CS_FRAC = CS_HID - 1ull;
 constexpr long long CS_BIG = 1ll << 53;
@@ -100,8 +105,8 @@ __global__ __launch_bounds__(256) void k_cs_links(int nchunks, int CH, const int
     lnk[(size_t)slot * (size_t)(nchunks + 1) + c] = out;
 }
 
-// One workgroup per (block of CS_E elements, tile).  The block's restart addends are staged in LDS (coalesced
-// loads); thread (rl, k) then walks its run of CS_R consecutive rows of seed k in row order, taking a row's links
+// One workgroup per (block of E elements, tile).  The block's restart addends are staged in LDS (coalesced
+// loads); thread (rl, k) then walks its run of R consecutive rows of seed k in row order, taking a row's links
 // into the seed before the row's restart addend; the runs are combined in row order by an LDS tree.
 template <int G, bool FUNCS>
 __global__ __launch_bounds__(256) void k_cs_block(int32_t n, int nchunks, const uint8_t *__restrict__ dangling,
@@ -113,6 +118,7 @@ __global__ __launch_bounds__(256) void k_cs_block(int32_t n, int nchunks, const 
                                                   double *__restrict__ approx, long long *__restrict__ od0,
                                                   long long *__restrict__ od1)
 {
+    constexpr int CS_E = CsGeom<G>::E, CS_R = CsGeom<G>::R;
     constexpr int CH = CS_E / G, RL = 256 / G;
     static_assert(CH == RL * CS_R, "run length");
     __shared__ double a_s[CS_E + CS_E / 16];
@@ -228,9 +234,12 @@ __device__ __forceinline__ double cs_from_m(int eb, long long M)
     return __longlong_as_double((long long)(((unsigned long long)eb << 52) | ((unsigned long long)M - CS_HID)));
 }
 
-// One wave redoes block c of seed kk exactly: lane = row, 64 rows at a time; inclusive scan of the rows' parity
-// functions under the CURRENT binade; at the first row that leaves the binade (or while s is zero / subnormal)
-// that row's adds are done in real fp64 and the scan restarts behind it.  Returns the new s (wave-uniform).
+// One wave redoes block c of seed kk exactly.  The block's CH rows are dealt to the lanes in runs of R = CH / 64
+// consecutive rows.  Under the CURRENT binade every lane composes its run's parity functions (a row's links into the
+// seed first, then its restart addend), one wave scan composes the runs, and the block is accepted up to the first
+// run that leaves the binade; that run's adds are then done in real fp64, row by row, and the lanes behind it
+// start over under the new binade.  While s is zero or subnormal the first run holding a non-zero addend is added
+// in real fp64 the same way.  Returns the new s (wave-uniform).
 template <int G>
 __device__ double cs_redo_block(double s, int32_t n, int nchunks, int c, int tile, int kk,
                                 const uint8_t *__restrict__ dangling, const double *__restrict__ X,
@@ -238,7 +247,8 @@ __device__ double cs_redo_block(double s, int32_t n, int nchunks, int c, int til
                                 const int32_t *__restrict__ in_src, const int64_t *__restrict__ evoff,
                                 const double *__restrict__ evterm, const int32_t *__restrict__ lnk)
 {
-    constexpr int CH = CS_E / G;
+    constexpr int CH = CsGeom<G>::CH, R = CH / WAVE;
+    static_assert(R >= 1 && R * WAVE == CH, "rows per lane");
     const int lane = threadIdx.x;
     const int slot = tile * G + kk;
     const int32_t sd = seeds[slot];
@@ -247,67 +257,89 @@ __device__ double cs_redo_block(double s, int32_t n, int nchunks, int c, int til
     const int32_t *srcp = in_src + in_ptr[sd];
     const double *termp = evterm + evoff[slot];
     const double *xk = X + (size_t)tile * (size_t)n * G + kk;
-    for (int sb = 0; sb < CH; sb += WAVE) {
-        const int64_t row = (int64_t)c * CH + sb + lane;
-        const bool inr = (sb + lane < CH) && row < n;
+    // the block's restart addends, fetched in one burst (16 loads in flight per lane) and parked in LDS (run-major reads
+    // are conflict-free with one pad slot per 64)
+    __shared__ double red_a[CH + CH / 64 + 1];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bool nzl = false;
+#pragma unroll 16
+    for (int i = lane; i < CH; i += WAVE) {
+        const int64_t row = (int64_t)c * CH + i;
         double a = 0.0;
-        int32_t lb = 0, le = 0;
-        if (inr) {
+        if (row < n) {
             const double xv = xk[(size_t)row * G];
-            const double rw = c1 * xv;
-            a = dangling[row] ? xv : (xv - rw);
-            if (a1 > a0) {
-                int32_t lo = a0, hi = a1;
-                while (lo < hi) {
-                    const int32_t mid = lo + ((hi - lo) >> 1);
-                    if ((int64_t)srcp[mid] < row) lo = mid + 1; else hi = mid;
-                }
-                lb = le = lo;
-                while (le < a1 && (int64_t)srcp[le] == row) ++le;
-            }
+            const double rw = c1 * xv;                         // Model.cs:84
+            a = dangling[row] ? xv : (xv - rw);                // Model.cs:97 / :91
         }
-        const bool haslink = le > lb;
-        int start = 0;
-        while (start < WAVE) {
-            const unsigned long long b = (unsigned long long)__double_as_longlong(s);
-            const int eb = (int)((b >> 52) & 0x7ff);
-            int L;
-            if (eb == 0 || eb == 0x7ff) {
-                // zero / subnormal (or non-finite) running sum: real adds; rows whose addends are all +0.0 are no-ops
-                const unsigned long long nzm = __ballot(lane >= start && (a != 0.0 || haslink));
-                if (!nzm) break;
-                L = __builtin_ctzll(nzm);
-            } else {
-                PF f{0, 0};
-                if (lane >= start) {
-                    for (int32_t q = lb; q < le; ++q) f = pf_compose(f, pf_of(termp[q], eb));
-                    f = pf_compose(f, pf_of(a, eb));
-                }
+        red_a[i + (i >> 6)] = a;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t row0 = (int64_t)c * CH + (int64_t)lane * R;   // first row of this lane's run
+    int32_t lb = a1;                                            // first link whose source row is >= row0
+    if (a1 > a0) {
+        int32_t lo = a0, hi = a1;
+        while (lo < hi) {
+            const int32_t mid = lo + ((hi - lo) >> 1);
+            if ((int64_t)srcp[mid] < row0) lo = mid + 1; else hi = mid;
+        }
+        lb = lo;
+    }
+    const bool haslink = lb < a1 && (int64_t)srcp[lb] < row0 + R;
 #pragma unroll
-                for (int off = 1; off < WAVE; off <<= 1) {
-                    PF o;
-                    o.d0 = __shfl_up(f.d0, off, WAVE);
-                    o.d1 = __shfl_up(f.d1, off, WAVE);
-                    if (lane >= off) f = pf_compose(o, f);
+    for (int u = 0; u < R; ++u) nzl = nzl || red_a[lane * R + u + ((lane * R + u) >> 6)] != 0.0;
+    nzl = nzl || haslink;
+    int start = 0;
+    while (start < WAVE) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(s);
+        const int eb = (int)((b >> 52) & 0x7ff);
+        int L;
+        if (eb == 0 || eb == 0x7ff) {
+            // zero / subnormal (or non-finite) running sum: real adds; runs whose addends are all +0.0 are no-ops
+            const unsigned long long nzm = __ballot(lane >= start && nzl);
+            if (!nzm) break;
+            L = __builtin_ctzll(nzm);
+        } else {
+            PF f{0, 0};
+            if (lane >= start) {
+                int32_t q = lb;
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    if (haslink)
+                        while (q < a1 && (int64_t)srcp[q] == row0 + u) { f = pf_compose(f, pf_of(termp[q], eb)); ++q; }
+                    f = pf_compose(f, pf_of(red_a[lane * R + u + ((lane * R + u) >> 6)], eb));
                 }
-                const long long m = (long long)((b & CS_FRAC) | CS_HID);
-                const long long M = m + ((m & 1) ? f.d1 : f.d0);
-                const unsigned long long cross = __ballot(M >= CS_BIG);
-                if (!cross) {
-                    s = cs_from_m(eb, __shfl(M, WAVE - 1, WAVE));
-                    break;
-                }
-                L = __builtin_ctzll(cross);
-                if (L > 0) s = cs_from_m(eb, __shfl(M, L - 1, WAVE));   // rows before the crossing (lanes < start hold m itself)
             }
-            double t = s;
-            if (lane == L) {
-                for (int32_t q = lb; q < le; ++q) t += termp[q];       // Model.cs:85-88
-                t += a;                                                // Model.cs:91-93,96-97
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                PF o;
+                o.d0 = __shfl_up(f.d0, off, WAVE);
+                o.d1 = __shfl_up(f.d1, off, WAVE);
+                if (lane >= off) f = pf_compose(o, f);
             }
-            s = __shfl(t, L, WAVE);
-            start = L + 1;
+            const long long m = (long long)((b & CS_FRAC) | CS_HID);
+            const long long M = m + ((m & 1) ? f.d1 : f.d0);
+            const unsigned long long cross = __ballot(M >= CS_BIG);
+            if (!cross) {
+                s = cs_from_m(eb, __shfl(M, WAVE - 1, WAVE));
+                break;
+            }
+            L = __builtin_ctzll(cross);
+            if (L > 0) s = cs_from_m(eb, __shfl(M, L - 1, WAVE));   // the runs before the crossing (lanes < start hold m itself)
         }
+        double t = s;
+        if (lane == L) {
+            int32_t q = lb;
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                if (haslink)
+                    while (q < a1 && (int64_t)srcp[q] == row0 + u) { t += termp[q]; ++q; }   // Model.cs:85-88
+                t += red_a[lane * R + u + ((lane * R + u) >> 6)];                              // Model.cs:91-93,96-97
+            }
+        }
+        s = __shfl(t, L, WAVE);
+        start = L + 1;
     }
     return s;
 }
@@ -388,7 +420,8 @@ __global__ __launch_bounds__(64) void k_cs_carry(int32_t n, int nchunks, const u
 
 // ---------------------------------------------------------------------------------------------- host side
 
-static inline int cs_nchunks(int32_t n, int G) { return (int)(((int64_t)n * G + CS_E - 1) / CS_E); }
+static inline int cs_block_elems(int G) { return G == 1 ? CsGeom<1>::E : CsGeom<2>::E; }
+static inline int cs_nchunks(int32_t n, int G) { return (int)(((int64_t)n * G + cs_block_elems(G) - 1) / cs_block_elems(G)); }
 
 #define CS_DISPATCH_G(G, CALL)                            \
     switch (G) {                                          \
@@ -416,7 +449,7 @@ int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, 
         RWR_HIP(hipMemsetAsync(g->cs_redo.p, 0, sizeof(unsigned long long), s));
     }
     hipLaunchKernelGGL(k_cs_links, dim3(cdiv((size_t)nchunks + 1, 256), (unsigned)(tg * G)), dim3(256), 0, s, nchunks,
-                       CS_E / G, g->in_ptr.p, g->in_src.p, d_seeds, g->cs_lnk.p);
+                       cs_block_elems(G) / G, g->in_ptr.p, g->in_src.p, d_seeds, g->cs_lnk.p);
     RWR_HIP(hipGetLastError());
     return RWR_OK;
 }
