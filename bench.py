@@ -166,6 +166,15 @@ def main():
                                    "call_wall": st["total_wall_ms"] / args.steps},
             "graph_build_ms": st["build_ms"], "graph_create_s": t_create,
         }
+        if world == 1:
+            # the unmodified harness's call shape (Experiment.cs:109): ONE seed per call.  Outside the timed region;
+            # reported beside the batch figure because it is what a drop-in user of the C# host sees per call.
+            s0 = int(seeds[len(seeds) // 2])
+            rec.Recommendation(s0, DAMPING, T_ITER, TOP_N)
+            t1 = time.perf_counter()
+            rec.Recommendation(s0, DAMPING, T_ITER, TOP_N)
+            out["single_seed_call"] = {"ms": 1e3 * (time.perf_counter() - t1), "seed": s0, "top_n": TOP_N,
+                                       "iterations": T_ITER, "mode": args.mode}
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(flat, seeds, ids, sc, cnt, args)
         print(json.dumps(out), flush=True)
