@@ -9,6 +9,7 @@
 // Header-only; link with librwr.so.
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -80,10 +81,24 @@ public:
             if (it == edges.end()) continue;
             for (const ForwardLink &l : it->second) { dst_[e] = l.targetNode; etype_[e] = (uint8_t)l.type; w[e] = l.weight; ++e; }
         }
+        // buildGraph() again after the host changed link types / weights in place (Experiment.cs:84-101 style): same nodes,
+        // list lengths and targets => only the changed links cross the boundary (rwr_graph_update_links)
+        if (h_ && id == sent_id_ && type == sent_type_ && rowptr == rowptr_ && dst_ == sent_dst_) {
+            std::vector<int64_t> idx;
+            std::vector<uint8_t> nt;
+            std::vector<double> nw;
+            for (size_t p = 0; p < w.size(); ++p)
+                if (etype_[p] != sent_etype_[p] || std::memcmp(&w[p], &sent_w_[p], sizeof(double)) != 0) {
+                    idx.push_back((int64_t)p); nt.push_back(etype_[p]); nw.push_back(w[p]);
+                }
+            check(rwr_graph_update_links(h_, (int64_t)idx.size(), idx.data(), nt.data(), nw.data()));
+        } else {
+            rwr_graph_destroy(h_);
+            h_ = nullptr;
+            check(rwr_graph_create(n, id.data(), type.data(), rowptr.data(), dst_.data(), etype_.data(), w.data(), nullptr, &h_));
+        }
         rowptr_ = rowptr;
-        rwr_graph_destroy(h_);
-        h_ = nullptr;
-        check(rwr_graph_create(n, id.data(), type.data(), rowptr.data(), dst_.data(), etype_.data(), w.data(), nullptr, &h_));
+        sent_id_ = id; sent_type_ = type; sent_dst_ = dst_; sent_etype_ = etype_; sent_w_ = w;
     }
 
     // the public field Graph.graph (Graph.cs:43): normalised explicit links per node; empty optional == null
@@ -116,6 +131,11 @@ private:
     std::vector<int64_t> rowptr_;
     std::vector<int32_t> dst_;
     std::vector<uint8_t> etype_;
+    // what the device currently holds (for the incremental rebuild)
+    std::vector<int64_t> sent_id_;
+    std::vector<uint8_t> sent_type_, sent_etype_;
+    std::vector<int32_t> sent_dst_;
+    std::vector<double> sent_w_;
 };
 
 class Model {                                                  // Model.cs:5-116

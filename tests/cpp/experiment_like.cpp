@@ -57,6 +57,26 @@ int main()
         EXPECT(model.rank[0] == 1.25 && model.rank[1] == 0.75);
         EXPECT(Recommender(graph).Recommendation(0, 0.5f, 3).empty());
     }
+    {   // buildGraph() again after an in-place relabel (Experiment.cs:84-101): the mirror sends only the changed link;
+        // KAT-1's path graph with the 2-3 like cut off becomes  0 <-> 1 <-> 2,  node 3 dangling
+        std::map<int, Node> nodes{{0, Node(10, NodeType::USER)}, {1, Node(11, NodeType::ITEM)},
+                                  {2, Node(12, NodeType::USER)}, {3, Node(13, NodeType::ITEM)}};
+        std::map<int, std::vector<ForwardLink>> edges;
+        auto like = [&](int a, int b) { edges[a].emplace_back(b, EdgeType::LIKE, 1.0); edges[b].emplace_back(a, EdgeType::LIKE, 1.0); };
+        like(0, 1); like(1, 2); like(2, 3);
+        Graph graph(nodes, edges);
+        graph.buildGraph();
+        rwr_graph *before = graph.handle();
+        for (auto &l : graph.edges[2]) if (l.targetNode == 3) l.type = EdgeType::UNDEFINED;
+        for (auto &l : graph.edges[3]) if (l.targetNode == 2) l.type = EdgeType::UNDEFINED;
+        graph.buildGraph();
+        EXPECT(graph.handle() == before);                        // patched in place, not re-created
+        auto norm = graph.graph();
+        EXPECT(norm[3] == nullptr && norm[2]->size() == 1 && (*norm[2])[0].weight == 1.0);
+        Model model(graph, 0.5, 0);
+        model.run(2);                                            // [4,0,0,0] -> [2,2,0,0] -> [2.5,1,0.5,0]
+        EXPECT(model.rank[0] == 2.5 && model.rank[1] == 1.0 && model.rank[2] == 0.5 && model.rank[3] == 0.0);
+    }
     std::puts("experiment_like: ok");
     return 0;
 }
