@@ -83,7 +83,6 @@ __global__ __launch_bounds__(256) void k_order_keys(int32_t n, const int64_t *__
                                                     const uint8_t *__restrict__ node_type,
                                                     const int64_t *__restrict__ node_id,
                                                     uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval,
-                                                    uint64_t *__restrict__ ikey, uint32_t *__restrict__ ival,
                                                     int *__restrict__ maxdeg, int order_mode)
 {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -93,10 +92,19 @@ __global__ __launch_bounds__(256) void k_order_keys(int32_t n, const int64_t *__
     // (stable, so rows keep their natural order inside a class); mode 1: natural order
     dkey[i] = (order_mode == 1) ? 0u : (order_mode == 2) ? ~(uint32_t)(32 - __clz((int)deg)) : ~deg;
     dval[i] = (uint32_t)i;
-    // items by id descending: ascending sort of ~orderable(id); non-items last
-    ikey[i] = (node_type[i] == RWR_NODE_ITEM) ? ~i64_orderable(node_id[i]) : ~0ull;
-    ival[i] = (uint32_t)i;
     atomicMax(maxdeg, (int)deg);
+}
+
+// items by id descending: ascending sort of ~orderable(id) over the ITEM rows only (every 64-bit key value is a
+// legitimate id -- INT64_MIN maps to ~0 -- so non-items cannot be parked behind a sentinel key)
+__global__ void k_item_id_keys(int32_t n_items, const int32_t *__restrict__ item_rows, const int64_t *__restrict__ node_id,
+                               uint64_t *__restrict__ ikey, uint32_t *__restrict__ ival)
+{
+    int32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_items) return;
+    const int32_t i = item_rows[q];
+    ikey[q] = ~i64_orderable(node_id[i]);
+    ival[q] = (uint32_t)i;
 }
 
 __global__ void k_item_flag_keys(int32_t n, const uint8_t *__restrict__ node_type, uint32_t *__restrict__ key,
@@ -280,7 +288,7 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     RWR_TRY(ival.alloc(n));
     RWR_TRY(ival2.alloc(n));
     hipLaunchKernelGGL(k_order_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->in_ptr.p, g->node_type.p,
-                       g->node_id.p, skey.p, sval.p, ikey.p, ival.p, flags.p + 2, order_mode);
+                       g->node_id.p, skey.p, sval.p, flags.p + 2, order_mode);
     RWR_HIP(hipGetLastError());
     RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, 32, temp.p, s, &alt));
     hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p, g->row_order.p,
@@ -292,10 +300,13 @@ static int32_t graph_derive(rwr_graph *g, bool first)
         if (n_items > 0)
             hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n_items, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p,
                                g->item_rows.p, (int64_t)n_items);
-        RWR_TRY(radix_sort_pairs<uint64_t>(ikey.p, ikey2.p, ival.p, ival2.p, (size_t)n, 1, 64, temp.p, s, &alt));
-        if (n_items > 0)
+        if (n_items > 0) {
+            hipLaunchKernelGGL(k_item_id_keys, dim3(cdiv(n_items, 256)), dim3(256), 0, s, n_items, g->item_rows.p,
+                               g->node_id.p, ikey.p, ival.p);
+            RWR_TRY(radix_sort_pairs<uint64_t>(ikey.p, ikey2.p, ival.p, ival2.p, (size_t)n_items, 1, 64, temp.p, s, &alt));
             hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n_items, 256)), dim3(256), 0, s, alt ? ival2.p : ival.p,
                                g->item_order.p, (int64_t)n_items);
+        }
     }
     RWR_HIP(hipGetLastError());
     RWR_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));

@@ -397,6 +397,18 @@ def test_degenerate_graphs(amd):
     G = dev_graph(amd, g)
     ids, sc, cnt = amd.Recommender(G).RecommendationBatch(np.array([0, 0, 0], dtype=np.int32), 0.15, 1, 5)
     assert cnt.tolist() == [0, 0, 0]
+    # an ITEM whose id is INT64_MIN (its id-descending sort key is all ones -- no sentinel may share it), among non-items
+    lo, hi = -2 ** 63, 2 ** 63 - 1
+    node_id = np.array([0, 1, -1, hi, lo, 3], dtype=np.int64)
+    node_type = np.array([gg.NODE_USER, gg.NODE_UNDEFINED, gg.NODE_ETC, gg.NODE_ITEM, gg.NODE_ITEM, gg.NODE_USER], dtype=np.uint8)
+    g = gg._from_lists(node_id, node_type, {i: [] for i in range(6)})
+    G = dev_graph(amd, g)
+    assert amd.Recommender(G).Recommendation(0, 0.15, 3) == [(hi, 0.0), (lo, 0.0)]
+    ids, sc, cnt = amd.Recommender(G).RecommendationBatch(np.array([0, 5, 0], dtype=np.int32), 0.15, 0, 5)
+    assert cnt.tolist() == [2, 2, 2] and ids[:, :2].tolist() == [[hi, lo]] * 3
+    F = FlatGraph(**g)
+    oi, os_, oc = F.recommend_batch(np.array([0, 5, 0], dtype=np.int32), 0.15, 0, 5)
+    assert (oi == ids).all() and (oc == cnt).all()
 
 
 @pytest.mark.parametrize("tile_seeds", [1, 8, 32])

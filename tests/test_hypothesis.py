@@ -1,6 +1,8 @@
 """Property-based checks: random small graphs with every feature the reference's containers allow --
 multi-edges, self-links, UNDEFINED links, zero/odd weights, arbitrary signed 64-bit ids, nodes of every type --
 run through both oracle restatements (CPU) and through the HIP path (GPU, bitwise in EXACT mode)."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
@@ -61,7 +63,7 @@ def test_two_restatements_agree_bitwise(case):
 
 
 @pytest.mark.gpu
-@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=int(os.environ.get("RWR_HYP_EXAMPLES", "60")), deadline=None, suppress_health_check=[HealthCheck.too_slow])
 @given(graphs())
 def test_hip_path_matches_literal_oracle_bitwise(case):
     import recommendersystems_amd as amd
