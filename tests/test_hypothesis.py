@@ -85,3 +85,43 @@ def test_hip_path_matches_literal_oracle_bitwise(case):
         assert (bits(sc[0, :cnt[0]]) == bits([x[1] for x in rec[:5]])).all()
     finally:
         G.close()
+
+
+@st.composite
+def patched_graphs(draw):
+    g, seed, T = draw(graphs())
+    m = len(g["dst"])
+    k = draw(st.integers(0, min(m, 6)))
+    idx = draw(st.lists(st.integers(0, max(m - 1, 0)), min_size=k, max_size=k, unique=True)) if m else []
+    new_t = [draw(st.sampled_from([0, 1, 2, 5])) for _ in idx]
+    new_w = [draw(st.sampled_from([1.0, 0.25, 4.0, 1e-3])) for _ in idx]
+    return g, seed, T, idx, new_t, new_w
+
+
+@pytest.mark.gpu
+@settings(max_examples=int(os.environ.get("RWR_HYP_EXAMPLES", "60")), deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(patched_graphs())
+def test_hip_incremental_rebuild_matches_literal_oracle(case):
+    """rwr_graph_update_links on random graphs: after patching a few links' types and weights the device state must be the
+    literal restatement's on the patched containers (ranks bitwise, ranked list identical)."""
+    import recommendersystems_amd as amd
+    g, seed, T, idx, new_t, new_w = case
+    G = amd.Graph.from_flat(**g)
+    G.buildGraph()
+    try:
+        et = g["etype"].copy()
+        w = g["w"].copy()
+        for p, t, x in zip(idx, new_t, new_w):
+            et[p] = t
+            w[p] = x
+        G.updateLinks(np.array(idx, dtype=np.int64), etype=np.array(new_t, dtype=np.uint8), w=np.array(new_w, dtype=np.float64))
+        g2 = dict(g, etype=et, w=w)
+        rank, rec = literal(g2, seed, T, dense=False)
+        m = amd.Model(G, po.widen_float(0.15), seed)
+        m.run(T)
+        assert (bits(m.rank) == bits(rank)).all()
+        got = amd.Recommender(G).Recommendation(seed, 0.15, T)
+        assert [x[0] for x in got] == [x[0] for x in rec]
+        assert (bits([x[1] for x in got]) == bits([x[1] for x in rec])).all()
+    finally:
+        G.close()
