@@ -32,6 +32,8 @@
 // Per-(seed, block) cells are laid out [slot][block] so that a window is one coalesced load.
 #include "engine.h"
 
+#include <cstdlib>
+
 namespace rwr {
 
 // rank-matrix elements per block (rows x G).  A single seed gets 1024-row blocks: a block that crosses a binade is
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(64) void k_cs_carry(int32_t n, int nchunks, const u
                                                  const int32_t *__restrict__ lnk, const double *__restrict__ approx,
                                                  const int32_t *__restrict__ e_pred, const long long *__restrict__ d0,
                                                  const long long *__restrict__ d1, uint32_t *__restrict__ nz_out,
-                                                 unsigned long long *__restrict__ redo_count)
+                                                 unsigned long long *__restrict__ redo_count, int direct)
 {
     const int slot = blockIdx.x, lane = threadIdx.x;
     const int tile = slot / G, k = slot % G;
@@ -362,6 +364,18 @@ __global__ __launch_bounds__(64) void k_cs_carry(int32_t n, int nchunks, const u
     const size_t base = (size_t)slot * nchunks;
     double s = 0.0;
     unsigned redo = 0;
+    if (direct) {
+        // a handful of blocks (ego-network sizes): nearly every block crosses a binade, so the parallel passes would be
+        // redone anyway -- the wave walks the blocks itself and the step saves three launches
+        for (int c = 0; c < nchunks; ++c)
+            s = cs_redo_block<G>(s, n, nchunks, c, tile, k, dangling, X, seeds, c1, in_ptr, in_src, evoff, evterm, lnk);
+        if (lane == 0) {
+            Y[(size_t)tile * (size_t)n * G + (size_t)sd * G + k] = s;
+            if (nz_out && s != 0.0)
+                atomicOr(&nz_out[(size_t)tile * (((size_t)n + 31) / 32) + ((uint32_t)sd >> 5)], 1u << (sd & 31));
+        }
+        return;
+    }
     // window registers: (block sum, predicted exponent, d0, d1) of block c + lane
     double ap, apn = 0.0;
     int32_t ep, epn = 0;
@@ -460,6 +474,14 @@ int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y,
 {
     const int nchunks = cs_nchunks(g->n, G);
     const dim3 grid((unsigned)nchunks, (unsigned)tg);
+    static const int direct_max = [] { const char *e = getenv("RWR_SCAN_DIRECT_BLOCKS"); return e ? atoi(e) : 8; }();
+    if (nchunks <= direct_max) {
+        CS_DISPATCH_G(G, hipLaunchKernelGGL(k_cs_carry<GG>, dim3((unsigned)(tg * G)), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y,
+                                            d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, g->cs_lnk.p,
+                                            g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, nz_out, g->cs_redo.p, 1));
+        RWR_HIP(hipGetLastError());
+        return RWR_OK;
+    }
     CS_DISPATCH_G(G, hipLaunchKernelGGL((k_cs_block<GG, false>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X,
                                         d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, g->cs_lnk.p,
                                         (const int32_t *)nullptr, g->cs_approx.p, (long long *)nullptr, (long long *)nullptr));
@@ -469,7 +491,7 @@ int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y,
                                         g->cs_e.p, (double *)nullptr, g->cs_d0.p, g->cs_d1.p));
     CS_DISPATCH_G(G, hipLaunchKernelGGL(k_cs_carry<GG>, dim3((unsigned)(tg * G)), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y,
                                         d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, g->cs_lnk.p,
-                                        g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, nz_out, g->cs_redo.p));
+                                        g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, nz_out, g->cs_redo.p, 0));
     RWR_HIP(hipGetLastError());
     return RWR_OK;
 }

@@ -848,16 +848,18 @@ __global__ void k_init_seeds(int32_t n, int ntiles, int G, double *__restrict__ 
 
 // Recommender.cs:20-24,29: the seed's RAW out-links of type LIKE are not candidates.
 // Marked by overwriting their (final) score with -1 -- valid scores are >= 0.
-__global__ void k_exclude(int32_t n, int ntiles, int G, const int64_t *__restrict__ rowptr,
-                          const int32_t *__restrict__ dst, const uint8_t *__restrict__ etype,
-                          double *__restrict__ X, const int32_t *__restrict__ seeds)
+__global__ __launch_bounds__(64) void k_exclude(int32_t n, int ntiles, int G, const int64_t *__restrict__ rowptr,
+                                                const int32_t *__restrict__ dst, const uint8_t *__restrict__ etype,
+                                                double *__restrict__ X, const int32_t *__restrict__ seeds)
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per seed slot, the lanes stride over the seed's raw out-links
+    const int q = blockIdx.x;
     if (q >= ntiles * G) return;
     const int32_t s = seeds[q];
     if (s < 0) return;
     double *x = X + (size_t)(q / G) * (size_t)n * G + (q % G);
-    for (int64_t p = rowptr[s]; p < rowptr[s + 1]; ++p)
+    const int64_t p1 = rowptr[s + 1];
+    for (int64_t p = rowptr[s] + threadIdx.x; p < p1; p += WAVE)
         if (etype[p] == RWR_EDGE_LIKE) x[(size_t)dst[p] * G] = -1.0;
 }
 
@@ -1336,7 +1338,7 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
         g->stats.spmm_seed_steps += (int64_t)real * n_iter;
         hipEvent_t a = nullptr, b = nullptr;
         if (prof) { a = pool.get(); b = pool.get(); RWR_HIP(hipEventRecord(a, s)); }
-        hipLaunchKernelGGL(k_exclude, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, g->rowptr.p,
+        hipLaunchKernelGGL(k_exclude, dim3((unsigned)(tg * G)), dim3(64), 0, s, n, tg, G, g->rowptr.p,
                            g->dst.p, g->etype.p, Xf, dseeds);
         RWR_HIP(hipGetLastError());
         static const int force_sort = [] { const char *e = getenv("RWR_RANK_SORT"); return e ? atoi(e) : 0; }();
@@ -1637,7 +1639,7 @@ int32_t part_rank(rwr_graph *g, double *x, int32_t top_n, int64_t *ids, double *
     RWR_HIP(hipMemsetAsync(g->d_out_id.p, 0, out_elems * sizeof(int64_t), s));
     RWR_HIP(hipMemsetAsync(g->d_out_score.p, 0, out_elems * sizeof(double), s));
     RWR_HIP(hipMemsetAsync(g->d_counts.p, 0, G * sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_exclude, dim3(1), dim3(64), 0, s, g->n, 1, G, g->rowptr.p, g->dst.p, g->etype.p, x, d_own.p);
+    hipLaunchKernelGGL(k_exclude, dim3((unsigned)G), dim3(64), 0, s, g->n, 1, G, g->rowptr.p, g->dst.p, g->etype.p, x, d_own.p);
     RWR_TRY(rank_group_select(g, G, 1, g->d_slot_k.p, top_n, x, d_own.p, s));
     std::vector<int32_t> hc((size_t)G);
     RWR_HIP(hipMemcpyAsync(hc.data(), g->d_counts.p, G * sizeof(int32_t), hipMemcpyDeviceToHost, s));
