@@ -1,5 +1,6 @@
 // Drop-in replacement of Recommenders/RWRBased/Model.cs: same public fields and methods; run*() execute on
-// the GPU through rwr_model_run and leave the result in `rank` exactly as the reference does.
+// the GPU through rwr_model_run and leave the result in `rank` exactly as the reference does; deliverRanks() is one
+// propagation on the GPU (rwr_model_deliver), updateRanks()/checkConvergence() are the reference's array loops.
 namespace Recommenders.RWRBased {
     public class Model {
         public Graph graph;
@@ -22,17 +23,53 @@ namespace Recommenders.RWRBased {
             for (int i = 0; i < nNodes; i++) { rank[i] = (i == targetNode) ? nNodes : 0; restart[i] = (i == targetNode) ? 1d : 0; }
         }
 
+        // rank / nextRank are still what the constructor left => the whole loop can stay on the device
+        bool CtorState() {
+            for (int i = 0; i < nNodes; i++) {
+                if (nextRank[i] != 0) return false;
+                double expect = seed < 0 ? 1d : (i == seed ? nNodes : 0d);
+                if (rank[i] != expect) return false;
+            }
+            return true;
+        }
+
         void Run(int mode, double value) {
-            long iters;
-            Native.Check(Native.rwr_model_run(graph.handle, seed, dampingFactor, mode, value, rank, out iters));
-            for (int i = 0; i < nNodes; i++) nextRank[i] = 0;
+            if (CtorState()) {
+                long iters;
+                Native.Check(Native.rwr_model_run(graph.handle, seed, dampingFactor, mode, value, rank, out iters));
+                for (int i = 0; i < nNodes; i++) nextRank[i] = 0;
+                return;
+            }
+            // an already advanced model: the reference's run() continues from the current rank (Model.cs:57-73)
+            if (mode == 0) {
+                for (int n = 0; n < (int)value; n++) { deliverRanks(); updateRanks(); }
+                return;
+            }
+            double threshold = mode == 2 ? (1 / double.MaxValue) * nNodes : value;
+            while (true) {
+                deliverRanks();
+                if (checkConvergence(threshold)) { updateRanks(); return; }
+                updateRanks();
+            }
         }
         public void run() { Run(2, 0); }
         public void run(double threshold) { Run(1, threshold); }
         public void run(int nIterations) { Run(0, nIterations); }
-        // single-step methods of the reference: one iteration == run(1)
-        public void deliverRanks() { throw new System.NotSupportedException("use run(int): deliverRanks+updateRanks are fused on the GPU"); }
-        public void updateRanks() { }
-        public bool checkConvergence(double threshold) { throw new System.NotSupportedException("use run(double)"); }
+
+        // the reference's public single steps (Model.cs:76,103,110)
+        public void deliverRanks() {
+            for (int i = 0; i < nNodes; i++)
+                if (nextRank[i] != 0)
+                    throw new System.InvalidOperationException("deliverRanks() on a non-zero nextRank: call updateRanks() first");
+            Native.Check(Native.rwr_model_deliver(graph.handle, seed, dampingFactor, rank, nextRank));
+        }
+        public void updateRanks() {
+            for (int i = 0; i < nNodes; i++) { rank[i] = nextRank[i]; nextRank[i] = 0; }
+        }
+        public bool checkConvergence(double threshold) {
+            double diff = 0;
+            for (int i = 0; i < nNodes; i++) diff += System.Math.Abs(rank[i] - nextRank[i]);
+            return diff < threshold;
+        }
     }
 }

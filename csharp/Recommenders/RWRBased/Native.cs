@@ -35,6 +35,8 @@ namespace Recommenders.RWRBased {
         [DllImport(Lib)] public static extern int rwr_model_run(GraphHandle g, int seed, double d, int run_mode, double value,
             double[] rank_out, out long iters_out);
 
+        [DllImport(Lib)] public static extern int rwr_model_deliver(GraphHandle g, int seed, double d, double[] rank, double[] next_rank);
+
         public static void Check(int status) {
             if (status == 0) return;
             string msg = Marshal.PtrToStringAnsi(rwr_last_error());

@@ -163,12 +163,56 @@ public:
     void run(int nIterations) { run_(RWR_RUN_ITERATIONS, nIterations); } // :68-73
     int64_t iterations = 0;
 
+    // the reference's public single steps
+    void deliverRanks()                                        // :76-100 -> rwr_model_deliver
+    {
+        for (double v : nextRank)
+            if (v != 0.0) throw std::logic_error("deliverRanks() on a non-zero nextRank: call updateRanks() first");
+        check(rwr_model_deliver(graph.handle(), seed_, dampingFactor, rank.data(), nextRank.data()));
+    }
+    void updateRanks()                                         // :103-108
+    {
+        for (int i = 0; i < nNodes; ++i) { rank[i] = nextRank[i]; nextRank[i] = 0.0; }
+    }
+    bool checkConvergence(double threshold) const              // :110-115
+    {
+        double diff = 0.0;
+        for (int i = 0; i < nNodes; ++i) diff += rank[i] > nextRank[i] ? rank[i] - nextRank[i] : nextRank[i] - rank[i];
+        return diff < threshold;
+    }
+
 private:
     int seed_;
+    bool ctor_state_() const
+    {
+        for (int i = 0; i < nNodes; ++i) {
+            if (nextRank[i] != 0.0) return false;
+            const double expect = seed_ < 0 ? 1.0 : (i == seed_ ? (double)nNodes : 0.0);
+            if (rank[i] != expect) return false;
+        }
+        return true;
+    }
     void run_(int mode, double value)
     {
-        check(rwr_model_run(graph.handle(), seed_, dampingFactor, mode, value, rank.data(), &iterations));
-        nextRank.assign(nNodes, 0.0);
+        if (ctor_state_()) {                                   // the whole loop stays on the device
+            check(rwr_model_run(graph.handle(), seed_, dampingFactor, mode, value, rank.data(), &iterations));
+            nextRank.assign(nNodes, 0.0);
+            return;
+        }
+        // an already advanced model: the reference's run() continues from the current rank (Model.cs:57-73)
+        iterations = 0;
+        if (mode == RWR_RUN_ITERATIONS) {
+            for (int64_t k = 0; k < (int64_t)value; ++k) { deliverRanks(); updateRanks(); ++iterations; }
+            return;
+        }
+        const double threshold = mode == RWR_RUN_DEFAULT_THRESHOLD ? (1 / 1.7976931348623157e308) * nNodes : value;
+        for (;;) {
+            deliverRanks();
+            ++iterations;
+            const bool done = checkConvergence(threshold);
+            updateRanks();
+            if (done) return;
+        }
     }
 };
 

@@ -198,6 +198,13 @@ int32_t rwr_recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, float
  * iters_out (optional) the number of deliverRanks() calls made. */
 int32_t rwr_model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double value,
                       double *rank_out, int64_t *iters_out);
+/* ONE Model.deliverRanks() (Model.cs:76-100) on a rank vector held by the caller: next_rank = what the reference would
+ * leave in nextRank (which updateRanks() has zeroed before, Model.cs:103-108) for the given rank.  Backs the public
+ * step-by-step API -- deliverRanks / updateRanks / checkConvergence (Model.cs:76,103,110) -- for a host that drives the
+ * loop itself; updateRanks and checkConvergence are array operations the shim does on its own copies.  seed >= 0:
+ * personalised restart vector e_seed (bitwise in EXACT mode, for any rank vector); seed == -1: the global model's
+ * uniform restart (tolerance parity, as rwr_model_run).  rank and next_rank hold n doubles and may not alias. */
+int32_t rwr_model_deliver(rwr_graph *g, int32_t seed, double d, const double *rank, double *next_rank);
 
 /* ---- row-partitioned mode (graphs beyond one GPU; BASELINE.json config 5) ------------
  * An ADDITION: the reference has no distributed mode.  The transition matrix is partitioned by SOURCE rows

@@ -19,7 +19,7 @@ RWR_RUN_ITERATIONS, RWR_RUN_THRESHOLD, RWR_RUN_DEFAULT_THRESHOLD = 0, 1, 2
 EXPORTS = [
     "rwr_version", "rwr_device_count", "rwr_last_error",
     "rwr_graph_create", "rwr_graph_update_links", "rwr_graph_destroy", "rwr_graph_size", "rwr_graph_get_normalized",
-    "rwr_recommend", "rwr_recommend_eval", "rwr_recommend_batch", "rwr_model_run",
+    "rwr_recommend", "rwr_recommend_eval", "rwr_recommend_batch", "rwr_model_run", "rwr_model_deliver",
     "rwr_part_begin", "rwr_part_local_step", "rwr_part_finish_step", "rwr_part_rank",
     "rwr_get_stats", "rwr_reset_stats",
 ]
@@ -85,6 +85,8 @@ def load():
     lib.rwr_model_run.restype = C.c_int32
     lib.rwr_model_run.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_double, p(C.c_double),
                                   p(C.c_int64)]
+    lib.rwr_model_deliver.restype = C.c_int32
+    lib.rwr_model_deliver.argtypes = [C.c_void_p, C.c_int32, C.c_double, p(C.c_double), p(C.c_double)]
     lib.rwr_part_begin.restype = C.c_int32
     lib.rwr_part_begin.argtypes = [C.c_void_p, C.c_int32, C.c_int32, p(C.c_int32), C.c_int32, C.c_double, C.c_void_p,
                                    p(C.c_int32)]

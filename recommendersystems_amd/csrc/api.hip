@@ -265,6 +265,14 @@ int32_t rwr_recommend_eval(rwr_graph *g, int32_t seed, float d, int32_t n_iter, 
     return RWR_OK;
 }
 
+int32_t rwr_model_deliver(rwr_graph *g, int32_t seed, double d, const double *rank, double *next_rank)
+{
+    g_err[0] = 0;
+    if (!g || !rank || !next_rank || rank == next_rank) { set_error("rwr_model_deliver: NULL or aliasing argument"); return RWR_E_INVALID; }
+    RWR_TRY(bind_device(g));
+    return model_deliver(g, seed, d, rank, next_rank);
+}
+
 int32_t rwr_model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double value, double *rank_out,
                       int64_t *iters_out)
 {

@@ -96,6 +96,7 @@ int32_t part_finish_step(rwr_graph *g, double *y, const double *r);
 int32_t part_rank(rwr_graph *g, double *x, int32_t top_n, int64_t *ids, double *scores, int32_t *counts);
 int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double value, double *rank_out,
                   int64_t *iters_out);
+int32_t model_deliver(rwr_graph *g, int32_t seed, double d, const double *rank_in, double *next_out);
 // chain_scan.hip: the exact seed-row chain as a parallel binade scan
 int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, hipStream_t s);
 int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,

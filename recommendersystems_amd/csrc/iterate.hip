@@ -1051,12 +1051,14 @@ struct GroupIter {
         : g(g_), G(G_), tg(tg_), d_seeds(seeds), d_evoff(evoff), c1(1 - d) /* Model.cs:84: (1 - dampingFactor) */,
           X(g_->X.p), Y(g_->Y.p) {}
 
-    int32_t init()
+    // fresh = Model ctor (rank = n at the seed, 0 elsewhere);  !fresh = X already holds a caller-supplied rank vector
+    // (Model.deliverRanks called on its own): no frontier knowledge, and the binade scan only if those ranks are >= 0
+    int32_t init(bool fresh = true, bool ranks_nonneg = true)
     {
         const int32_t n = g->n;
         hipStream_t s = g->stream;
         const size_t elems = (size_t)tg * (size_t)n * G;
-        RWR_HIP(hipMemsetAsync(X, 0, elems * sizeof(double), s));
+        if (fresh) RWR_HIP(hipMemsetAsync(X, 0, elems * sizeof(double), s));
         // frontier bitmaps for the first iterations (chunked SpMM only)
         static const int nz_iters_env = [] { const char *e = getenv("RWR_NZ_ITERS"); return e ? atoi(e) : 4; }();
         static const int spmm_variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
@@ -1069,11 +1071,12 @@ struct GroupIter {
         act_iters = act_env >= 0 ? act_env : ((g->nnz / (g->n > 0 ? g->n : 1)) <= 64 ? 2 : 1);
         // single exact seed (lane-per-row SpMV): row-level skipping only, for exactly those iterations
         if (G == 1 && tg == 1 && spmm_variant != 0 && g->nonneg && g->opts.mode != RWR_MODE_FAST) nz_iters = act_iters;
+        if (!fresh) nz_iters = act_iters = 0;
         const size_t nzw = ((size_t)n + 31) / 32;
         nz_cur = nz_iters > 0 ? g->d_nz.p : nullptr;
         nz_oth = nz_iters > 0 ? g->d_nz.p + (size_t)tg * nzw : nullptr;
         if (nz_cur) RWR_HIP(hipMemsetAsync(nz_cur, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(k_init_seeds, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, X, d_seeds, nz_cur);
+        if (fresh) hipLaunchKernelGGL(k_init_seeds, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, X, d_seeds, nz_cur);
         RWR_HIP(hipGetLastError());
         it = 0;
         // Seed-row chain of the dense iterations.  The role-specialised fold (k_seed_chain_roles) takes ~20 cycles per
@@ -1089,7 +1092,7 @@ struct GroupIter {
         const int sel = g->opts.seed_row_kernel;
         chain_kind = sel == 1 ? 3 : sel == 2 ? 2 : sel == 3 ? 0 : chain_env;
         const double per_seed = 0.89 * (double)g->nnz / (double)(g->n > 0 ? g->n : 1) + 6.7;
-        scan = g->opts.mode != RWR_MODE_FAST && c1 >= 0.0 && c1 <= 1.0 && g->nonneg &&
+        scan = g->opts.mode != RWR_MODE_FAST && c1 >= 0.0 && c1 <= 1.0 && g->nonneg && ranks_nonneg &&
                (chain_kind == 2 || (chain_kind == 1 && (double)tg * G * per_seed < scan_work));
         if (scan) RWR_TRY(chain_scan_prepare(g, G, tg, d_seeds, s));
         return RWR_OK;
@@ -1517,6 +1520,52 @@ int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double
     RWR_HIP(hipStreamSynchronize(s));
     RWR_HIP(hipStreamSynchronize(g->stream2));
     if (iters_out) *iters_out = done;
+    return RWR_OK;
+}
+
+// One Model.deliverRanks (Model.cs:76-100) on a rank vector supplied by the caller: backs the public step-by-step API
+// (deliverRanks / updateRanks / checkConvergence, Model.cs:76,103,110) for hosts that drive the loop themselves.
+int32_t model_deliver(rwr_graph *g, int32_t seed, double d, const double *rank_in, double *next_out)
+{
+    const int32_t n = g->n;
+    if (seed < -1 || seed >= n) {
+        set_error("seed %d is outside [0, %d) (and is not -1 = global model)", seed, n);
+        return RWR_E_RANGE;
+    }
+    int TG = 1;
+    RWR_TRY(ensure_workspace(g, 1, 1, &TG));
+    hipStream_t s = g->stream;
+    bool nonneg = true;
+    for (int32_t i = 0; i < n; ++i)
+        if (!(rank_in[i] >= 0.0)) { nonneg = false; break; }
+    RWR_HIP(hipMemcpyAsync(g->X.p, rank_in, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    double *out = nullptr;
+    if (seed >= 0) {
+        RWR_TRY(upload_seed_slots(g, &seed, 1, 1, nullptr));
+        EvPool pool;
+        std::vector<hipEvent_t> a, b;
+        GroupIter gi(g, 1, 1, g->d_seeds.p, g->d_evoff.p, d);
+        RWR_TRY(gi.init(false, nonneg));
+        RWR_TRY(gi.step(pool, a, b));
+        RWR_HIP(hipStreamSynchronize(s));
+        RWR_HIP(hipStreamSynchronize(g->stream2));
+        out = gi.X;                                   // (step() swapped: X holds nextRank)
+    } else {
+        RWR_TRY(g->d_part.ensure(RED_GRID + 8));
+        double *part = g->d_part.p, *scalar = g->d_part.p + RED_GRID;
+        const double c1 = 1 - d, inv_n = 1.0 / n;
+        int32_t no_seed = -1;
+        RWR_TRY(g->d_seeds.ensure(1));
+        RWR_HIP(hipMemcpyAsync(g->d_seeds.p, &no_seed, sizeof(int32_t), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_rr_partial, dim3(RED_GRID), dim3(256), 0, s, g->X.p, g->dangling.p, n, c1, part);
+        hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(1), 0, s, part, RED_GRID, scalar);
+        launch_spmm<1>(g, 1, g->X.p, g->Y.p, g->d_seeds.p, c1, 0, nullptr, nullptr, s);
+        hipLaunchKernelGGL(k_add_restart_share, dim3(cdiv((size_t)n, 256)), dim3(256), 0, s, g->Y.p, n, scalar, inv_n);
+        RWR_HIP(hipGetLastError());
+        out = g->Y.p;
+    }
+    RWR_HIP(hipMemcpyAsync(next_out, out, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipStreamSynchronize(s));
     return RWR_OK;
 }
 

@@ -239,8 +239,22 @@ class Model:
         self.nextRank = np.zeros(n)
         self.iterations = 0
 
+    def _ctor_state(self) -> bool:
+        """rank / nextRank / restart are still what the constructor left (then the whole run can stay on the device)."""
+        n = self.nNodes
+        if self.nextRank.shape != (n,) or self.rank.shape != (n,) or np.any(self.nextRank != 0):
+            return False
+        if self._seed < 0:
+            return bool(np.all(self.rank == 1.0))
+        if not (0 <= self._seed < n):
+            return bool(np.all(self.rank == 0.0))
+        r = self.rank
+        return bool(r[self._seed] == float(n) and np.count_nonzero(r) == (1 if n else 0))
+
     def run(self, arg=None) -> None:
-        """run(int) / run(double) / run()  (Model.cs:68-73, 57-66, 52-55)."""
+        """run(int) / run(double) / run()  (Model.cs:68-73, 57-66, 52-55).  From the constructor's state the whole loop
+        runs on the device (rwr_model_run); on a model that has already been advanced -- the reference's run() continues
+        from the current rank -- it is driven step by step through deliverRanks / updateRanks / checkConvergence."""
         lib = _lib.load()
         if isinstance(arg, (int, np.integer)) and not isinstance(arg, bool):
             mode, value = _lib.RWR_RUN_ITERATIONS, float(arg)
@@ -248,6 +262,24 @@ class Model:
             mode, value = _lib.RWR_RUN_DEFAULT_THRESHOLD, 0.0
         else:
             mode, value = _lib.RWR_RUN_THRESHOLD, float(arg)
+        if not self._ctor_state():
+            if mode == _lib.RWR_RUN_ITERATIONS:                  # Model.cs:68-73
+                for _ in range(int(value)):
+                    self.deliverRanks()
+                    self.updateRanks()
+                self.iterations = int(value)
+                return
+            threshold = (1.0 / 1.7976931348623157e308) * self.nNodes if mode == _lib.RWR_RUN_DEFAULT_THRESHOLD else value
+            it = 0
+            while True:                                          # Model.cs:57-66
+                self.deliverRanks()
+                it += 1
+                done = self.checkConvergence(threshold)
+                self.updateRanks()
+                if done:
+                    break
+            self.iterations = it
+            return
         out = np.zeros(self.nNodes, dtype=np.float64)
         it = C.c_int64(0)
         _lib.check(lib.rwr_model_run(self.graph._handle(), self._seed, self.dampingFactor, mode, value,
@@ -255,6 +287,34 @@ class Model:
         self.rank = out
         self.nextRank = np.zeros(self.nNodes)
         self.iterations = int(it.value)
+
+    def deliverRanks(self) -> None:
+        """Model.deliverRanks (Model.cs:76-100): nextRank <- one propagation of the current rank (rwr_model_deliver)."""
+        n = self.nNodes
+        if np.any(self.nextRank != 0):
+            raise RuntimeError("deliverRanks() on a non-zero nextRank (the reference would add on top of it): call updateRanks() first")
+        expect = np.full(n, 1.0 / n) if self._seed < 0 else np.zeros(n)
+        if 0 <= self._seed < n:
+            expect[self._seed] = 1.0
+        if not np.array_equal(np.asarray(self.restart, dtype=np.float64), expect):
+            raise RuntimeError("Model.restart was modified: only the constructors' restart vectors are supported")
+        rank = np.ascontiguousarray(self.rank, dtype=np.float64)
+        out = np.empty(n, dtype=np.float64)
+        _lib.check(_lib.load().rwr_model_deliver(self.graph._handle(), self._seed, self.dampingFactor,
+                                                 _p(rank, C.c_double), _p(out, C.c_double)))
+        self.nextRank = out
+
+    def updateRanks(self) -> None:
+        """Model.updateRanks (Model.cs:103-108)."""
+        self.rank = np.array(self.nextRank, dtype=np.float64)
+        self.nextRank = np.zeros(self.nNodes)
+
+    def checkConvergence(self, threshold: float) -> bool:
+        """Model.checkConvergence (Model.cs:110-115): sequential sum of |rank - nextRank| < threshold."""
+        if self.nNodes == 0:
+            return 0.0 < threshold
+        diff = np.cumsum(np.abs(np.asarray(self.rank, dtype=np.float64) - self.nextRank))   # cumsum adds left to right
+        return bool(diff[-1] < threshold)
 
 
 class Recommender:

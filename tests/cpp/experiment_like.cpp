@@ -30,6 +30,12 @@ int main()
         Model model(graph, 0.5, 0);
         model.run(3);
         EXPECT(model.rank[0] == 2.25 && model.rank[1] == 1.375 && model.rank[2] == 0.25 && model.rank[3] == 0.125);
+        Model stepwise(graph, 0.5, 0);                           // the same three iterations, driven step by step
+        stepwise.deliverRanks();
+        EXPECT(stepwise.nextRank[0] == 2.0 && stepwise.nextRank[1] == 2.0 && !stepwise.checkConvergence(3.9) && stepwise.checkConvergence(4.1));
+        stepwise.updateRanks();
+        stepwise.run(2);                                         // continues from the advanced state
+        EXPECT(stepwise.rank == model.rank);
         Recommender recommender(graph);
         auto recommendation = recommender.Recommendation(0, 0.5f, 3);
         EXPECT(recommendation.size() == 1 && recommendation[0].first == 13 && recommendation[0].second == 0.125);

@@ -669,3 +669,52 @@ def test_negative_weights_take_the_general_path(amd):
             amd.Recommender(G).Recommendation(0, 0.15, 5)
         assert ei.value.status == 7 and "non-negative" in str(ei.value)
         G.close()
+
+
+@pytest.mark.parametrize("case", SMALL[:3] + MEDIUM[:1], ids=lambda c: f"g{c['seed']}")
+def test_model_stepwise_public_api(amd, case):
+    """Model.deliverRanks / updateRanks / checkConvergence as separate public steps (Model.cs:76,103,110), driven by the
+    host exactly as the reference allows: every intermediate nextRank bitwise, checkConvergence identical; run() on an
+    already advanced model CONTINUES from its rank (Model.cs:68-73); a rank vector edited by the host (halved, with a
+    negative entry) still propagates bitwise (general kernels)."""
+    g = gg.random_graph(**case)
+    nodes, edges = po.from_flat(g["node_id"], g["node_type"], g["rowptr"], g["dst"], g["etype"], g["w"])
+    PG = po.Graph(nodes, edges)
+    PG.buildGraph()
+    G = dev_graph(amd, g)
+    d = po.widen_float(0.15)
+    seed = case["n_users"] // 2
+    ref, dev = po.Model(PG, d, seed, dense_restart=False), amd.Model(G, d, seed)
+    for step in range(4):
+        ref.deliverRanks(); dev.deliverRanks()
+        assert (bits(dev.nextRank) == bits(ref.nextRank)).all(), step
+        for thr in (1e-300, 0.5, 10.0, 1e9):
+            assert dev.checkConvergence(thr) == ref.checkConvergence(thr)
+        with pytest.raises(RuntimeError):
+            dev.deliverRanks()                                   # nextRank not yet folded into rank
+        ref.updateRanks(); dev.updateRanks()
+        assert (bits(dev.rank) == bits(ref.rank)).all() and not dev.nextRank.any()
+    # run(int) continues from the current state
+    a, b = po.Model(PG, d, seed, dense_restart=False), amd.Model(G, d, seed)
+    a.run(3); b.run(3)
+    a.run(2); b.run(2)
+    fresh = amd.Model(G, d, seed); fresh.run(5)
+    assert (bits(b.rank) == bits(a.rank)).all() and (bits(b.rank) == bits(fresh.rank)).all()
+    # threshold run on an advanced model: same number of further iterations, same ranks
+    it_ref = a.run(1e-3); b.run(1e-3)
+    assert b.iterations == it_ref and (bits(b.rank) == bits(a.rank)).all()
+    # host-edited rank vector (public field): halved, one entry negative
+    a, b = po.Model(PG, d, seed, dense_restart=False), amd.Model(G, d, seed)
+    a.run(2); b.run(2)
+    for m in (a, b):
+        m.rank = [x * 0.5 for x in m.rank] if isinstance(m.rank, list) else m.rank * 0.5
+        m.rank[1] = -0.75
+    a.deliverRanks(); b.deliverRanks()
+    assert (bits(b.nextRank) == bits(np.array(a.nextRank))).all()
+    # global model: tolerance parity per step
+    ga, gb = po.Model(PG, d), amd.Model(G, d)
+    for _ in range(3):
+        ga.deliverRanks(); gb.deliverRanks()
+        assert np.allclose(gb.nextRank, np.array(ga.nextRank), rtol=1e-12, atol=1e-12)
+        ga.updateRanks(); gb.updateRanks()
+    G.close()
