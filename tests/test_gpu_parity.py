@@ -718,3 +718,22 @@ def test_model_stepwise_public_api(amd, case):
         assert np.allclose(gb.nextRank, np.array(ga.nextRank), rtol=1e-12, atol=1e-12)
         ga.updateRanks(); gb.updateRanks()
     G.close()
+
+
+@pytest.mark.parametrize("d", [0.0, 1.0, 0.999, 1e-7])
+def test_extreme_restart_probabilities(amd, d):
+    """d = 0 (no restart: the chain only carries dangling mass), d = 1 (no walk), and values next to them: single seed
+    (binade scan) and batch (both seed-row kernels) stay bitwise equal to the restatement."""
+    g = gg.random_graph(8, n_users=300, n_items=900, n_likes=5000, n_etc=10, n_friend=200, n_mention=100)
+    F = FlatGraph(**g)
+    seeds = np.array([0, 5, 150, 299], dtype=np.int32)
+    oi, os_, oc = F.recommend_batch(seeds, d, 7, 20)
+    for kern in ("scan", "fold"):
+        G = dev_graph(amd, g, seed_row_kernel=kern)
+        ids, sc, cnt = amd.Recommender(G).RecommendationBatch(seeds, d, 7, 20)
+        assert (cnt == oc).all() and (ids == oi).all() and (bits(sc) == bits(os_)).all(), kern
+        m = amd.Model(G, po.widen_float(d), 5)
+        m.run(7)
+        r, _ = F.model_run(po.widen_float(d), 5, 0, 7)
+        assert (bits(m.rank) == bits(r)).all(), kern
+        G.close()
