@@ -88,17 +88,16 @@ __global__ __launch_bounds__(256) void k_spmm(int32_t n, const int64_t *__restri
 // entry through the L1), and keeps the 8 gathers of x in flight before the first dependent add.
 typedef int v4i_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
-__global__ __launch_bounds__(256) void k_spmv_exact(int32_t r0, int32_t n, const int64_t *__restrict__ in_ptr,
-                                                    const int32_t *__restrict__ in_src,
-                                                    const double *__restrict__ in_w,
-                                                    const int32_t *__restrict__ row_order,
-                                                    const double *__restrict__ x, double *__restrict__ y,
-                                                    const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
-                                                    const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
+// (bid, nblk): this workgroup's index and the number of workgroups serving the bin -- the four bins share ONE launch
+// (k_spmv_exact_binned below), so that their tails overlap instead of queueing behind each other
+__device__ __forceinline__ void spmv_exact_lane(int bid, int nblk, int32_t r0, int32_t n, const int64_t *__restrict__ in_ptr,
+                                                const int32_t *__restrict__ in_src, const double *__restrict__ in_w,
+                                                const int32_t *__restrict__ row_order, const double *__restrict__ x,
+                                                double *__restrict__ y, int32_t my_seed, double c1,
+                                                const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
 {
-    const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t r = (int64_t)r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+    const int64_t stride = (int64_t)nblk * blockDim.x;
+    for (int64_t r = (int64_t)r0 + (int64_t)bid * blockDim.x + threadIdx.x; r < n; r += stride) {
         const int32_t j = row_order[r];
         int64_t p = in_ptr[j];
         int64_t e = in_ptr[j + 1];
@@ -124,9 +123,20 @@ __global__ __launch_bounds__(256) void k_spmv_exact(int32_t r0, int32_t n, const
             rw = c1 * x6; acc += rw * w3.x;
             rw = c1 * x7; acc += rw * w3.y;
         }
-        for (; p < e; ++p) {
-            const double rw = c1 * x[in_src[p]];
-            acc += rw * in_w[p];
+        {   // the last (up to 7) entries: all loads issued before the first dependent add
+            const int cnt = (int)(e - p);
+            int32_t ti[7];
+            double tw[7], tx[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                ti[u] = u < cnt ? in_src[p + u] : 0;
+                tw[u] = u < cnt ? in_w[p + u] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 7; ++u) tx[u] = u < cnt ? x[ti[u]] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                if (u < cnt) { const double rw = c1 * tx[u]; acc += rw * tw[u]; }
         }
         if (j != my_seed) y[j] = acc;
         if (nz_out && acc != 0.0) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
@@ -145,18 +155,15 @@ __device__ __forceinline__ double readlane_f64(double v, int t)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), t);
     return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(256) void k_spmv_exact_wave(int32_t r1, const int64_t *__restrict__ in_ptr,
-                                                         const int32_t *__restrict__ in_src,
-                                                         const double *__restrict__ in_w,
-                                                         const int32_t *__restrict__ row_order,
-                                                         const double *__restrict__ x, double *__restrict__ y,
-                                                         const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
-                                                         const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
+__device__ __forceinline__ void spmv_exact_wave(int bid, int nblk, int32_t r1, const int64_t *__restrict__ in_ptr,
+                                                const int32_t *__restrict__ in_src, const double *__restrict__ in_w,
+                                                const int32_t *__restrict__ row_order, const double *__restrict__ x,
+                                                double *__restrict__ y, int32_t my_seed, double c1,
+                                                const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) / WAVE;
-    for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE; r < r1; r += nwaves) {
+    const int64_t nwaves = ((int64_t)nblk * blockDim.x) / WAVE;
+    for (int64_t r = ((int64_t)bid * blockDim.x + threadIdx.x) / WAVE; r < r1; r += nwaves) {
         const int32_t j = row_order[r];
         int64_t p = in_ptr[j];
         int64_t e = in_ptr[j + 1];
@@ -195,19 +202,16 @@ __global__ __launch_bounds__(256) void k_spmv_exact_wave(int32_t r1, const int64
 // formed in parallel; every lane of the group then adds them in list order (the group's lanes all carry the row's
 // accumulator), taking product t from lane t of its group.
 template <int W>
-__global__ __launch_bounds__(256) void k_spmv_exact_group(int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
-                                                          const int32_t *__restrict__ in_src,
-                                                          const double *__restrict__ in_w,
-                                                          const int32_t *__restrict__ row_order,
-                                                          const double *__restrict__ x, double *__restrict__ y,
-                                                          const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
-                                                          const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
+__device__ __forceinline__ void spmv_exact_group(int bid, int nblk, int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
+                                                 const int32_t *__restrict__ in_src, const double *__restrict__ in_w,
+                                                 const int32_t *__restrict__ row_order, const double *__restrict__ x,
+                                                 double *__restrict__ y, int32_t my_seed, double c1,
+                                                 const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
 {
     constexpr int RPW = WAVE / W;
     const int lane = threadIdx.x & (WAVE - 1), gl = lane % W, grp = lane / W;
-    const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) / WAVE;
-    for (int64_t rb = (int64_t)r0 + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE) * RPW; rb < r1; rb += nwaves * RPW) {
+    const int64_t nwaves = ((int64_t)nblk * blockDim.x) / WAVE;
+    for (int64_t rb = (int64_t)r0 + (((int64_t)bid * blockDim.x + threadIdx.x) / WAVE) * RPW; rb < r1; rb += nwaves * RPW) {
         const int64_t r = rb + grp;
         int32_t j = -1;
         int64_t p = 0, e = 0;
@@ -245,6 +249,28 @@ __global__ __launch_bounds__(256) void k_spmv_exact_group(int32_t r0, int32_t r1
             if (nz_out && acc != 0.0) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
         }
     }
+}
+
+// rows [0, b0): a wave per row; [b0, b1): 16 lanes per row; [b1, b2): 4 lanes per row; [b2, n): a lane per row.
+// Workgroups [0, nb0) serve the first bin, the next nb1 the second, ...
+__global__ __launch_bounds__(256) void k_spmv_exact_binned(int nb0, int nb1, int nb2, int nb3, int32_t b0, int32_t b1, int32_t b2,
+                                                           int32_t n, const int64_t *__restrict__ in_ptr,
+                                                           const int32_t *__restrict__ in_src,
+                                                           const double *__restrict__ in_w,
+                                                           const int32_t *__restrict__ row_order,
+                                                           const double *__restrict__ x, double *__restrict__ y,
+                                                           const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
+                                                           const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
+{
+    const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
+    int b = blockIdx.x;
+    if (b < nb0) { spmv_exact_wave(b, nb0, b0, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out); return; }
+    b -= nb0;
+    if (b < nb1) { spmv_exact_group<16>(b, nb1, b0, b1, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out); return; }
+    b -= nb1;
+    if (b < nb2) { spmv_exact_group<4>(b, nb2, b1, b2, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out); return; }
+    b -= nb2;
+    spmv_exact_lane(b, nb3, b2, n, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out);
 }
 
 // K = 1, FAST mode: the classic vector-CSR SpMV.  W lanes share one destination row: each lane streams every W-th
@@ -884,27 +910,16 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
             // rows are in in-degree order (unless RWR_ROW_ORDER says otherwise): the first bin_end[0] have >= 128 in-links
             static const bool by_degree = [] { const char *e = getenv("RWR_ROW_ORDER"); return !e || atoi(e) == 0; }();
             // in-degree >= 128: a wave per row; >= 32: 16 lanes per row; >= 4: 4 lanes per row; below: a lane per row
-            // (RWR_GROUP_ROWS = 0 keeps everything under 128 on the lane-per-row kernel)
+            // (RWR_GROUP_ROWS = 0 keeps everything under 128 on the lane-per-row form); one launch for all bins
             static const int group_rows = [] { const char *e = getenv("RWR_GROUP_ROWS"); return e ? atoi(e) : 2; }();
             const int32_t b0 = by_degree ? g->bin_end[0] : 0;
             const int32_t b1 = (by_degree && group_rows >= 1) ? g->bin_end[1] : b0;
             const int32_t b2 = (by_degree && group_rows >= 2) ? g->bin_end[2] : b1;
-            const int32_t r_long = b2;
-            auto blocks_for = [](int64_t rows, int W) { const int64_t b = (rows * W + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); };
-            if (b0 > 0)
-                hipLaunchKernelGGL(k_spmv_exact_wave, dim3(blocks_for(b0, 64)), dim3(256), 0, s, b0, g->in_ptr.p,
-                                   g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, act, nz_out);
-            if (b1 > b0)
-                hipLaunchKernelGGL(k_spmv_exact_group<16>, dim3(blocks_for(b1 - b0, 16)), dim3(256), 0, s, b0, b1, g->in_ptr.p,
-                                   g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, act, nz_out);
-            if (b2 > b1)
-                hipLaunchKernelGGL(k_spmv_exact_group<4>, dim3(blocks_for(b2 - b1, 4)), dim3(256), 0, s, b1, b2, g->in_ptr.p,
-                                   g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, act, nz_out);
-            if (g->n > r_long) {
-                const unsigned blocks = cdiv((size_t)(g->n - r_long), 256);
-                hipLaunchKernelGGL(k_spmv_exact, dim3(blocks < 16384u ? blocks : 16384u), dim3(256), 0, s, r_long, g->n,
-                                   g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, act, nz_out);
-            }
+            auto blocks_for = [](int64_t rows, int W) { const int64_t b = (rows * W + 255) / 256; return (int)(b < 0 ? 0 : (b > 16384 ? 16384 : b)); };
+            const int nb0 = blocks_for(b0, 64), nb1 = blocks_for(b1 - b0, 16), nb2 = blocks_for(b2 - b1, 4), nb3 = blocks_for(g->n - b2, 1);
+            if (nb0 + nb1 + nb2 + nb3 > 0)
+                hipLaunchKernelGGL(k_spmv_exact_binned, dim3((unsigned)(nb0 + nb1 + nb2 + nb3)), dim3(256), 0, s, nb0, nb1, nb2, nb3, b0,
+                                   b1, b2, g->n, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, act, nz_out);
             return;
         }
     }
