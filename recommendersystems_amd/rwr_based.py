@@ -341,6 +341,23 @@ class Recommender:
         c = int(cnt.value)
         return list(zip(ids[:c].tolist(), sc[:c].tolist()))
 
+    def RecommendationArrays(self, idxTargetUser: int, dampingFactor: float, nIteration: int,
+                             topN: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """The same ranked list as Recommendation(), as two arrays (ids, scores) -- for graphs whose full list has
+        millions of entries, where building Python tuples costs far more than the GPU call."""
+        g = self.graph
+        if g.edges is not None and idxTargetUser not in g.edges:
+            raise KeyError(idxTargetUser)
+        cap = g.size() if topN is None or topN <= 0 else min(g.size(), int(topN))
+        ids = np.empty(max(cap, 1), dtype=np.int64)
+        sc = np.empty(max(cap, 1), dtype=np.float64)
+        cnt = C.c_int64(cap)
+        _lib.check(_lib.load().rwr_recommend(g._handle(), int(idxTargetUser), C.c_float(dampingFactor), int(nIteration),
+                                             0 if topN is None else int(topN), _p(ids, C.c_int64), _p(sc, C.c_double),
+                                             C.byref(cnt)))
+        c = int(cnt.value)
+        return ids[:c], sc[:c]
+
     def RecommendationEval(self, idxTargetUser: int, dampingFactor: float, nIteration: int, testSet):
         """Recommendation + the harness's evaluation of it (Experiment.cs:109,121-128) without bringing the list
         to the host: returns (nHits, sumPrecision, len(list)); MAP contribution = sumPrecision / nHits."""

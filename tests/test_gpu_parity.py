@@ -97,6 +97,8 @@ def test_small_exact_bitwise_vs_literal_python(amd, case, tile_seeds, seed_row_k
         assert rec.Recommendation(seed, 0.15, 10, 7) == got[:7]
         assert rec.Recommendation(seed, 0.15, 10, 0) == got          # topN <= 0 -> whole list
         assert rec.Recommendation(seed, 0.15, 10, 10 ** 6) == got
+        ai, asc = rec.RecommendationArrays(seed, 0.15, 10)
+        assert ai.tolist() == [r[0] for r in got] and asc.tolist() == [r[1] for r in got]
 
 
 @pytest.mark.parametrize("case", MEDIUM, ids=lambda c: f"g{c['seed']}")
