@@ -902,7 +902,9 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
     static const int variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
     if constexpr (G == 1) {
         // single seed, FAST mode: vector-CSR SpMV (re-associated sums are allowed there); EXACT keeps lane = row
-        if (g->opts.mode == RWR_MODE_FAST && tg == 1 && !skip && variant != 0) {
+        // (the first iterations, while most rows are still exactly 0, run on the list-order kernels below, which
+        //  know how to skip rows without a non-zero in-neighbour: a list-order sum is a valid FAST result)
+        if (g->opts.mode == RWR_MODE_FAST && tg == 1 && !skip && variant != 0 && !act && !nz_out) {
             launch_spmv_vector(g, X, Y, c1, s);
             return;
         }
@@ -1085,7 +1087,7 @@ struct GroupIter {
         static const int act_env = [] { const char *e = getenv("RWR_ACT_ITERS"); return e ? atoi(e) : -1; }();
         act_iters = act_env >= 0 ? act_env : ((g->nnz / (g->n > 0 ? g->n : 1)) <= 64 ? 2 : 1);
         // single exact seed (lane-per-row SpMV): row-level skipping only, for exactly those iterations
-        if (G == 1 && tg == 1 && spmm_variant != 0 && g->nonneg && g->opts.mode != RWR_MODE_FAST) nz_iters = act_iters;
+        if (G == 1 && tg == 1 && spmm_variant != 0 && g->nonneg) nz_iters = act_iters;
         if (!fresh) nz_iters = act_iters = 0;
         const size_t nzw = ((size_t)n + 31) / 32;
         nz_cur = nz_iters > 0 ? g->d_nz.p : nullptr;
