@@ -97,6 +97,10 @@ int32_t part_rank(rwr_graph *g, double *x, int32_t top_n, int64_t *ids, double *
 int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double value, double *rank_out,
                   int64_t *iters_out);
 int32_t model_deliver(rwr_graph *g, int32_t seed, double d, const double *rank_in, double *next_out);
+// spmv.hip: single-seed SpMV (EXACT: list-order sums, rows binned by in-degree; FAST: vector-CSR with tree reductions)
+void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *seeds, double c1, int skip,
+                       const uint32_t *act, uint32_t *nz_out, hipStream_t s);
+void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hipStream_t s);
 // chain_scan.hip: the exact seed-row chain as a parallel binade scan
 int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, hipStream_t s);
 int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,

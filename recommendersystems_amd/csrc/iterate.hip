@@ -81,283 +81,6 @@ __global__ __launch_bounds__(256) void k_spmm(int32_t n, const int64_t *__restri
     }
 }
 
-// K = 1, EXACT mode: one lane per destination row, the row's in-list walked sequentially in the reference's addend
-// order (bitwise).  Rows come in in-degree order, so the lanes of a wave have lists of similar length.  Each lane
-// streams ITS list with wide loads -- 8 indices as two 16-byte loads, 8 weights as four -- so a fetched 64-byte
-// sector is consumed whole by the lane that fetched it (per-entry 4- and 8-byte loads would move one sector per
-// entry through the L1), and keeps the 8 gathers of x in flight before the first dependent add.
-typedef int v4i_u __attribute__((ext_vector_type(4), aligned(4)));
-typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
-// (bid, nblk): this workgroup's index and the number of workgroups serving the bin -- the four bins share ONE launch
-// (k_spmv_exact_binned below), so that their tails overlap instead of queueing behind each other
-__device__ __forceinline__ void spmv_exact_lane(int bid, int nblk, int32_t r0, int32_t n, const int64_t *__restrict__ in_ptr,
-                                                const int32_t *__restrict__ in_src, const double *__restrict__ in_w,
-                                                const int32_t *__restrict__ row_order, const double *__restrict__ x,
-                                                double *__restrict__ y, int32_t my_seed, double c1,
-                                                const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
-{
-    const int64_t stride = (int64_t)nblk * blockDim.x;
-    for (int64_t r = (int64_t)r0 + (int64_t)bid * blockDim.x + threadIdx.x; r < n; r += stride) {
-        const int32_t j = row_order[r];
-        int64_t p = in_ptr[j];
-        int64_t e = in_ptr[j + 1];
-        // first iterations: a row none of whose in-neighbours holds a non-zero (k_mark_active) stays exactly +0.0
-        if (act && !((act[(uint32_t)j >> 5] >> (j & 31)) & 1u)) e = p;
-        double acc = 0.0;
-        for (; p + 8 <= e; p += 8) {
-            const v4i_u i0 = *reinterpret_cast<const v4i_u *>(in_src + p);
-            const v4i_u i1 = *reinterpret_cast<const v4i_u *>(in_src + p + 4);
-            const v2d_u w0 = *reinterpret_cast<const v2d_u *>(in_w + p);
-            const v2d_u w1 = *reinterpret_cast<const v2d_u *>(in_w + p + 2);
-            const v2d_u w2 = *reinterpret_cast<const v2d_u *>(in_w + p + 4);
-            const v2d_u w3 = *reinterpret_cast<const v2d_u *>(in_w + p + 6);
-            const double x0 = x[i0.x], x1 = x[i0.y], x2 = x[i0.z], x3 = x[i0.w];
-            const double x4 = x[i1.x], x5 = x[i1.y], x6 = x[i1.z], x7 = x[i1.w];
-            double rw;
-            rw = c1 * x0; acc += rw * w0.x;      // Model.cs:84,87 -- in list order
-            rw = c1 * x1; acc += rw * w0.y;
-            rw = c1 * x2; acc += rw * w1.x;
-            rw = c1 * x3; acc += rw * w1.y;
-            rw = c1 * x4; acc += rw * w2.x;
-            rw = c1 * x5; acc += rw * w2.y;
-            rw = c1 * x6; acc += rw * w3.x;
-            rw = c1 * x7; acc += rw * w3.y;
-        }
-        {   // the last (up to 7) entries: all loads issued before the first dependent add
-            const int cnt = (int)(e - p);
-            int32_t ti[7];
-            double tw[7], tx[7];
-#pragma unroll
-            for (int u = 0; u < 7; ++u) {
-                ti[u] = u < cnt ? in_src[p + u] : 0;
-                tw[u] = u < cnt ? in_w[p + u] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 7; ++u) tx[u] = u < cnt ? x[ti[u]] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 7; ++u)
-                if (u < cnt) { const double rw = c1 * tx[u]; acc += rw * tw[u]; }
-        }
-        if (j != my_seed) y[j] = acc;
-        if (nz_out && acc != 0.0) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
-    }
-}
-
-// K = 1, EXACT mode, LONG rows (in-degree >= 128: hub items, the ego of an ego network): one lane walking such a list
-// alone pays a memory round trip per few entries and the longest row becomes the kernel's run time.  Here a whole wave
-// serves the row: 64 consecutive entries are loaded coalesced, their 64 gathers of x fly together and the products
-// rw * weight (Model.cs:84,87) are formed in parallel -- only the ADDS stay sequential, in list order, each taking
-// the next product from its lane (v_readlane) into the wave-uniform accumulator:  8 cycles per entry instead of a
-// memory latency, bit for bit the same sum.  The next 64 entries are fetched while the adds of the current ones run.
-__device__ __forceinline__ double readlane_f64(double v, int t)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), t);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), t);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ void spmv_exact_wave(int bid, int nblk, int32_t r1, const int64_t *__restrict__ in_ptr,
-                                                const int32_t *__restrict__ in_src, const double *__restrict__ in_w,
-                                                const int32_t *__restrict__ row_order, const double *__restrict__ x,
-                                                double *__restrict__ y, int32_t my_seed, double c1,
-                                                const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
-{
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int64_t nwaves = ((int64_t)nblk * blockDim.x) / WAVE;
-    for (int64_t r = ((int64_t)bid * blockDim.x + threadIdx.x) / WAVE; r < r1; r += nwaves) {
-        const int32_t j = row_order[r];
-        int64_t p = in_ptr[j];
-        int64_t e = in_ptr[j + 1];
-        if (act && !((act[(uint32_t)j >> 5] >> (j & 31)) & 1u)) e = p;
-        double acc = 0.0;
-        double cur = 0.0;
-        if (p + lane < e) {
-            const double rw = c1 * x[in_src[p + lane]];
-            cur = rw * in_w[p + lane];
-        }
-        while (p < e) {
-            const int64_t pn = p + WAVE;
-            double nxt = 0.0;
-            if (pn + lane < e) {                       // issued ahead of the dependent adds below
-                const double rw = c1 * x[in_src[pn + lane]];
-                nxt = rw * in_w[pn + lane];
-            }
-            if (e - p >= WAVE) {
-#pragma unroll
-                for (int t = 0; t < WAVE; ++t) acc += readlane_f64(cur, t);
-            } else {
-                const int cnt = (int)(e - p);
-                for (int t = 0; t < cnt; ++t) acc += __shfl(cur, t, WAVE);
-            }
-            cur = nxt;
-            p = pn;
-        }
-        if (lane == 0) {
-            if (j != my_seed) y[j] = acc;
-            if (nz_out && acc != 0.0) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
-        }
-    }
-}
-
-// The same idea for shorter rows: W (16 or 4) lanes share a row, 64 / W rows per wave.  The W products of a round are
-// formed in parallel; every lane of the group then adds them in list order (the group's lanes all carry the row's
-// accumulator), taking product t from lane t of its group.
-template <int W>
-__device__ __forceinline__ void spmv_exact_group(int bid, int nblk, int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
-                                                 const int32_t *__restrict__ in_src, const double *__restrict__ in_w,
-                                                 const int32_t *__restrict__ row_order, const double *__restrict__ x,
-                                                 double *__restrict__ y, int32_t my_seed, double c1,
-                                                 const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
-{
-    constexpr int RPW = WAVE / W;
-    const int lane = threadIdx.x & (WAVE - 1), gl = lane % W, grp = lane / W;
-    const int64_t nwaves = ((int64_t)nblk * blockDim.x) / WAVE;
-    for (int64_t rb = (int64_t)r0 + (((int64_t)bid * blockDim.x + threadIdx.x) / WAVE) * RPW; rb < r1; rb += nwaves * RPW) {
-        const int64_t r = rb + grp;
-        int32_t j = -1;
-        int64_t p = 0, e = 0;
-        if (r < r1) {
-            j = row_order[r];
-            p = in_ptr[j];
-            e = in_ptr[j + 1];
-            if (act && !((act[(uint32_t)j >> 5] >> (j & 31)) & 1u)) e = p;
-        }
-        double acc = 0.0;
-        double cur = 0.0;
-        if (p + gl < e) {
-            const double rw = c1 * x[in_src[p + gl]];
-            cur = rw * in_w[p + gl];
-        }
-        while (__any(p < e)) {
-            const int64_t pn = p + W;
-            double nxt = 0.0;
-            if (pn + gl < e) {
-                const double rw = c1 * x[in_src[pn + gl]];
-                nxt = rw * in_w[pn + gl];
-            }
-            const int64_t left = e - p;
-            const int cnt = left > W ? W : (left > 0 ? (int)left : 0);
-#pragma unroll
-            for (int t = 0; t < W; ++t) {
-                const double v = __shfl(cur, t, W);
-                if (t < cnt) acc += v;
-            }
-            cur = nxt;
-            if (p < e) p = pn;
-        }
-        if (gl == 0 && j >= 0) {
-            if (j != my_seed) y[j] = acc;
-            if (nz_out && acc != 0.0) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
-        }
-    }
-}
-
-// rows [0, b0): a wave per row; [b0, b1): 16 lanes per row; [b1, b2): 4 lanes per row; [b2, n): a lane per row.
-// Workgroups [0, nb0) serve the first bin, the next nb1 the second, ...
-__global__ __launch_bounds__(256) void k_spmv_exact_binned(int nb0, int nb1, int nb2, int nb3, int32_t b0, int32_t b1, int32_t b2,
-                                                           int32_t n, const int64_t *__restrict__ in_ptr,
-                                                           const int32_t *__restrict__ in_src,
-                                                           const double *__restrict__ in_w,
-                                                           const int32_t *__restrict__ row_order,
-                                                           const double *__restrict__ x, double *__restrict__ y,
-                                                           const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
-                                                           const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
-{
-    const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
-    int b = blockIdx.x;
-    if (b < nb0) { spmv_exact_wave(b, nb0, b0, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out); return; }
-    b -= nb0;
-    if (b < nb1) { spmv_exact_group<16>(b, nb1, b0, b1, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out); return; }
-    b -= nb1;
-    if (b < nb2) { spmv_exact_group<4>(b, nb2, b1, b2, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out); return; }
-    b -= nb2;
-    spmv_exact_lane(b, nb3, b2, n, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out);
-}
-
-// K = 1, FAST mode: the classic vector-CSR SpMV.  W lanes share one destination row: each lane streams every W-th
-// entry of the row's in-list (coalesced index and weight reads), gathers x, keeps a private partial sum, and the W
-// partials are combined with a shuffle butterfly whose shape depends only on W -- rows of equal structure get
-// bit-identical results, so structural ties stay tied.  The summation order differs from the reference's, which is
-// why this kernel exists only in FAST mode (scores within 1e-6).  Rows are binned by in-degree (row_order is sorted
-// by it): W = 64 / 16 / 4 / 1.
-template <int W>
-__global__ __launch_bounds__(256) void k_spmv_vector(int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
-                                                     const int32_t *__restrict__ in_src,
-                                                     const double *__restrict__ in_w,
-                                                     const int32_t *__restrict__ row_order,
-                                                     const double *__restrict__ x, double *__restrict__ y, double c1)
-{
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int l = (int)(gid % W);
-    for (int64_t r = r0 + gid / W; r < r1; r += ((int64_t)gridDim.x * blockDim.x) / W) {
-        const int32_t j = row_order[r];
-        const int64_t p0 = in_ptr[j], p1 = in_ptr[j + 1];
-        double acc = 0.0;
-        int64_t p = p0 + l;
-        for (; p + 3 * W < p1; p += 4 * W) {               // four independent gathers in flight per lane
-            const double a0 = c1 * x[in_src[p]], a1 = c1 * x[in_src[p + W]];
-            const double a2 = c1 * x[in_src[p + 2 * W]], a3 = c1 * x[in_src[p + 3 * W]];
-            acc += a0 * in_w[p];
-            acc += a1 * in_w[p + W];
-            acc += a2 * in_w[p + 2 * W];
-            acc += a3 * in_w[p + 3 * W];
-        }
-        for (; p < p1; p += W) acc += (c1 * x[in_src[p]]) * in_w[p];
-#pragma unroll
-        for (int off = W / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, W);
-        if (l == 0) y[j] = acc;
-    }
-}
-
-// very long rows (in-degree >= 2048): a whole 1024-thread workgroup per row; per-lane partials, shuffle butterfly per
-// wave, then the 16 wave sums are staged in LDS and added in wave order
-__global__ __launch_bounds__(1024) void k_spmv_row_block(int32_t r1, const int64_t *__restrict__ in_ptr,
-                                                         const int32_t *__restrict__ in_src,
-                                                         const double *__restrict__ in_w,
-                                                         const int32_t *__restrict__ row_order,
-                                                         const double *__restrict__ x, double *__restrict__ y, double c1)
-{
-    __shared__ double wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int32_t r = blockIdx.x; r < r1; r += gridDim.x) {
-        const int32_t j = row_order[r];
-        const int64_t p0 = in_ptr[j], p1 = in_ptr[j + 1];
-        double acc = 0.0;
-        int64_t p = p0 + tid;
-        for (; p + 3 * 1024 < p1; p += 4 * 1024) {
-            const double a0 = c1 * x[in_src[p]], a1 = c1 * x[in_src[p + 1024]];
-            const double a2 = c1 * x[in_src[p + 2048]], a3 = c1 * x[in_src[p + 3072]];
-            acc += a0 * in_w[p];
-            acc += a1 * in_w[p + 1024];
-            acc += a2 * in_w[p + 2048];
-            acc += a3 * in_w[p + 3072];
-        }
-        for (; p < p1; p += 1024) acc += (c1 * x[in_src[p]]) * in_w[p];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane == 0) wsum[wv] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-            for (int q = 0; q < 16; ++q) t += wsum[q];
-            y[j] = t;
-        }
-        __syncthreads();
-    }
-}
-
-static void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hipStream_t s)
-{
-    const int32_t n = g->n, bh = g->bin_huge, b0 = g->bin_end[0], b1 = g->bin_end[1], b2 = g->bin_end[2];
-    if (bh > 0)
-        hipLaunchKernelGGL(k_spmv_row_block, dim3(bh < 4096 ? bh : 4096), dim3(1024), 0, s, bh, g->in_ptr.p, g->in_src.p,
-                           g->in_w.p, g->row_order.p, x, y, c1);
-    auto grid = [](int64_t rows, int W) { int64_t blocks = (rows * W + 255) / 256; return (unsigned)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks)); };
-    if (b0 > bh) hipLaunchKernelGGL(k_spmv_vector<64>, dim3(grid(b0 - bh, 64)), dim3(256), 0, s, bh, b0, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, x, y, c1);
-    if (b1 > b0) hipLaunchKernelGGL(k_spmv_vector<16>, dim3(grid(b1 - b0, 16)), dim3(256), 0, s, b0, b1, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, x, y, c1);
-    if (b2 > b1) hipLaunchKernelGGL(k_spmv_vector<4>, dim3(grid(b2 - b1, 4)), dim3(256), 0, s, b1, b2, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, x, y, c1);
-    if (n > b2) hipLaunchKernelGGL(k_spmv_vector<1>, dim3(grid(n - b2, 1)), dim3(256), 0, s, b2, n, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, x, y, c1);
-}
-
 // Chunked variant for G >= 8: a lane group fetches G consecutive in-neighbour indices (and
 // weights) of its row with ONE coalesced load -- lane k takes entry p+k -- and hands entry t
 // to the whole group through the LDS crossbar (ds_bpermute), instead of G lanes loading the
@@ -909,19 +632,7 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
             return;
         }
         if (tg == 1 && variant != 0) {
-            // rows are in in-degree order (unless RWR_ROW_ORDER says otherwise): the first bin_end[0] have >= 128 in-links
-            static const bool by_degree = [] { const char *e = getenv("RWR_ROW_ORDER"); return !e || atoi(e) == 0; }();
-            // in-degree >= 128: a wave per row; >= 32: 16 lanes per row; >= 4: 4 lanes per row; below: a lane per row
-            // (RWR_GROUP_ROWS = 0 keeps everything under 128 on the lane-per-row form); one launch for all bins
-            static const int group_rows = [] { const char *e = getenv("RWR_GROUP_ROWS"); return e ? atoi(e) : 2; }();
-            const int32_t b0 = by_degree ? g->bin_end[0] : 0;
-            const int32_t b1 = (by_degree && group_rows >= 1) ? g->bin_end[1] : b0;
-            const int32_t b2 = (by_degree && group_rows >= 2) ? g->bin_end[2] : b1;
-            auto blocks_for = [](int64_t rows, int W) { const int64_t b = (rows * W + 255) / 256; return (int)(b < 0 ? 0 : (b > 16384 ? 16384 : b)); };
-            const int nb0 = blocks_for(b0, 64), nb1 = blocks_for(b1 - b0, 16), nb2 = blocks_for(b2 - b1, 4), nb3 = blocks_for(g->n - b2, 1);
-            if (nb0 + nb1 + nb2 + nb3 > 0)
-                hipLaunchKernelGGL(k_spmv_exact_binned, dim3((unsigned)(nb0 + nb1 + nb2 + nb3)), dim3(256), 0, s, nb0, nb1, nb2, nb3, b0,
-                                   b1, b2, g->n, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, act, nz_out);
+            launch_spmv_exact(g, X, Y, seeds, c1, skip, act, nz_out, s);
             return;
         }
     }
