@@ -88,12 +88,24 @@ __device__ __forceinline__ void spmv_exact_wave(int bid, int nblk, int32_t r1, c
                                                 double *__restrict__ y, int32_t my_seed, double c1,
                                                 const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
 {
+    // the 64 products of a round are parked in LDS (double-buffered per wave); every lane then reads them back one by
+    // one from the SAME address (a broadcast read, no bank conflict) -- one LDS read + one add per entry, and the reads
+    // of a round are independent of its adds, so they run ahead of them
+    __shared__ double prod_s[4][2][WAVE];
     const int lane = threadIdx.x & (WAVE - 1);
+    double(*pb)[WAVE] = prod_s[threadIdx.x / WAVE];
     const int64_t nwaves = ((int64_t)nblk * blockDim.x) / WAVE;
-    for (int64_t r = ((int64_t)bid * blockDim.x + threadIdx.x) / WAVE; r < r1; r += nwaves) {
-        const int32_t j = row_order[r];
-        int64_t p = in_ptr[j];
-        int64_t e = in_ptr[j + 1];
+    int buf = 0;
+    int64_t r = ((int64_t)bid * blockDim.x + threadIdx.x) / WAVE;
+    int32_t j = -1;
+    int64_t p = 0, e = 0;
+    if (r < r1) { j = row_order[r]; p = in_ptr[j]; e = in_ptr[j + 1]; }
+    for (; r < r1; r += nwaves) {
+        // the NEXT row's index and list bounds are fetched while this row is being summed
+        const int64_t rn = r + nwaves;
+        int32_t jn = -1;
+        int64_t pn_ = 0, en_ = 0;
+        if (rn < r1) { jn = row_order[rn]; pn_ = in_ptr[jn]; en_ = in_ptr[jn + 1]; }
         if (act && !((act[(uint32_t)j >> 5] >> (j & 31)) & 1u)) e = p;
         double acc = 0.0;
         double cur = 0.0;
@@ -108,13 +120,17 @@ __device__ __forceinline__ void spmv_exact_wave(int bid, int nblk, int32_t r1, c
                 const double rw = c1 * x[in_src[pn + lane]];
                 nxt = rw * in_w[pn + lane];
             }
+            pb[buf][lane] = cur;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             if (e - p >= WAVE) {
 #pragma unroll
-                for (int t = 0; t < WAVE; ++t) acc += readlane_f64(cur, t);
+                for (int t = 0; t < WAVE; ++t) acc += pb[buf][t];
             } else {
                 const int cnt = (int)(e - p);
-                for (int t = 0; t < cnt; ++t) acc += __shfl(cur, t, WAVE);
+                for (int t = 0; t < cnt; ++t) acc += pb[buf][t];
             }
+            buf ^= 1;                                  // (the other buffer: no wait for this round's reads before the next write)
             cur = nxt;
             p = pn;
         }
@@ -122,6 +138,7 @@ __device__ __forceinline__ void spmv_exact_wave(int bid, int nblk, int32_t r1, c
             if (j != my_seed) y[j] = acc;
             if (nz_out && acc != 0.0) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
         }
+        j = jn; p = pn_; e = en_;
     }
 }
 
