@@ -232,11 +232,14 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     DevBuf<uint32_t> skey, skey2, sval, sval2;
     DevBuf<uint8_t> temp;
     DevBuf<int> flags;
+    // the (key, value) buffers serve the link sort (m entries) AND, afterwards, the row-order / item sorts (n entries):
+    // a graph may have fewer links than nodes
+    const size_t kv = (size_t)(m > (int64_t)n ? m : (int64_t)n);
     RWR_TRY(esrc.alloc(m));
-    RWR_TRY(skey.alloc(m));
-    RWR_TRY(skey2.alloc(m));
-    RWR_TRY(sval.alloc(m));
-    RWR_TRY(sval2.alloc(m));
+    RWR_TRY(skey.alloc(kv));
+    RWR_TRY(skey2.alloc(kv));
+    RWR_TRY(sval.alloc(kv));
+    RWR_TRY(sval2.alloc(kv));
     RWR_TRY(flags.alloc(4));
     size_t tbytes = radix_sort_temp_bytes((size_t)m, 1);
     size_t tb2 = radix_sort_temp_bytes((size_t)n, 1);

@@ -739,3 +739,37 @@ def test_extreme_restart_probabilities(amd, d):
         r, _ = F.model_run(po.widen_float(d), 5, 0, 7)
         assert (bits(m.rank) == bits(r)).all(), kern
         G.close()
+
+
+def test_fewer_links_than_nodes(amd):
+    """Mostly isolated nodes (links << nodes): the build's sort buffers serve the link sort AND the node-order sorts, so
+    they must be sized for the larger of the two (they once were sized by the links alone: rows went missing from the
+    processing order).  Dangling seed through the single-seed path (no shortcut), live seeds, batch."""
+    rng = np.random.default_rng(5)
+    U, I = 6000, 9000
+    lists = {i: [] for i in range(U + I)}
+    for _ in range(700):
+        u, v = int(rng.integers(0, U)), int(rng.integers(0, I))
+        if U + v not in lists[u]:
+            lists[u].append(U + v); lists[U + v].append(u)
+    node_id = rng.permutation(U + I).astype(np.int64)
+    node_type = np.array([gg.NODE_USER] * U + [gg.NODE_ITEM] * I, dtype=np.uint8)
+    g = gg._from_lists(node_id, node_type, lists)
+    assert len(g["dst"]) < U + I
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g)
+    live = [u for u in range(U) if lists[u]][:3]
+    dead = [u for u in range(U) if not lists[u]][:2]
+    for sd in live + dead:
+        for T in (1, 2, 3, 6):
+            m = amd.Model(G, po.widen_float(0.15), sd)
+            m.run(T)
+            r, _ = F.model_run(po.widen_float(0.15), sd, 0, T)
+            assert (bits(m.rank) == bits(r)).all(), (sd, T)
+        got = amd.Recommender(G).Recommendation(sd, 0.15, 5, 30)
+        oi, os_ = F.recommend(sd, 0.15, 5, 30)
+        assert [x[0] for x in got] == oi.tolist() and (bits([x[1] for x in got]) == bits(os_)).all()
+    seeds = np.array(live + dead, dtype=np.int32)
+    ids, sc, cnt = amd.Recommender(G).RecommendationBatch(seeds, 0.15, 6, 30)
+    oi, os_, oc = F.recommend_batch(seeds, 0.15, 6, 30)
+    assert (cnt == oc).all() and (ids == oi).all() and (bits(sc) == bits(os_)).all()

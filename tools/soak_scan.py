@@ -1,0 +1,58 @@
+"""Differential soak of the two seed-row kernels (sequential fold vs parallel binade scan) and the C restatement on random
+graphs whose weights span many binades: every run must agree bit for bit.   python tools/soak_scan.py [seconds]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from recommendersystems_amd.rwr_based import Graph, Model, Recommender
+from oracle.c_oracle import FlatGraph
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+t_end = time.time() + budget
+base = int(os.environ.get("SOAK_SEED", "20261004"))
+first = int(os.environ.get("SOAK_FIRST", "0"))
+runs = 0
+while time.time() < t_end:
+    rng = np.random.default_rng(base + first + runs)          # one generator per case: a failure is reproducible by its number
+    U = int(rng.integers(50, 20000)); I = int(rng.integers(50, 40000)); E = int(rng.integers(U, 12 * (U + I)))
+    n = U + I
+    us = (rng.random(E) ** rng.uniform(1, 3) * U).astype(np.int64)
+    vs = (rng.random(E) ** rng.uniform(1, 3) * I).astype(np.int64)
+    key = np.unique(us * I + vs)
+    us, vs = key // I, key % I
+    span = int(rng.integers(0, 40))
+    wu = np.where(rng.random(len(key)) < 0.5, 2.0 ** rng.integers(-span, span + 1, len(key)),
+                  rng.random(len(key)) * 2.0 ** rng.integers(-span, span + 1, len(key)))
+    src = np.concatenate([us, U + vs]); dst = np.concatenate([U + vs, us]); w = np.concatenate([wu, np.ones(len(key))])
+    et = np.where(rng.random(len(src)) < 0.03, 0, 1).astype(np.uint8)
+    order = np.lexsort((rng.random(len(src)), src))                       # random list order inside a source
+    src, dst, w, et = src[order], dst[order], w[order], et[order]
+    rowptr = np.zeros(n + 1, dtype=np.int64); np.add.at(rowptr, src + 1, 1); rowptr = np.cumsum(rowptr)
+    g = dict(node_id=rng.permutation(n).astype(np.int64), node_type=np.array([1] * U + [2] * I, dtype=np.uint8),
+             rowptr=rowptr, dst=dst.astype(np.int32), etype=et, w=w.astype(np.float64))
+    F = FlatGraph(**g)
+    K = int(rng.choice([1, 2, 5, 16, 40]))
+    seeds = rng.integers(0, U, K).astype(np.int32)
+    T = int(rng.integers(1, 12)); d = float(rng.choice([0.15, 0.5, 0.01, 0.85]))
+    oi, os_, oc = F.recommend_batch(seeds, d, T, 20)
+    for kern in ("scan", "fold"):
+        G = Graph.from_flat(**g, seed_row_kernel=kern, tile_seeds=int(rng.choice([0, 1, 8, 32])) if K > 1 else 0)
+        G.buildGraph()
+        ids, sc, cnt = Recommender(G).RecommendationBatch(seeds, d, T, 20)
+        ok_b = bool((cnt == oc).all() and (ids == oi).all() and (sc.view(np.uint64) == os_.view(np.uint64)).all())
+        m = Model(G, float(np.float32(d)), int(seeds[0])); m.run(T)
+        r, _ = F.model_run(float(np.float32(d)), int(seeds[0]), 0, T)
+        bad = np.flatnonzero(m.rank.view(np.uint64) != r.view(np.uint64))
+        st = G.stats()
+        G.close()
+        if not ok_b or len(bad):
+            print("MISMATCH case", first + runs, kern, dict(U=U, I=I, E=len(key), K=K, T=T, d=d, span=span, G=st["tile_seeds"]),
+                  "batch ok", ok_b, "cnt", (cnt == oc).all(), "ids", (ids == oi).all(),
+                  "rows with differing scores", np.flatnonzero((sc.view(np.uint64) != os_.view(np.uint64)).any(axis=1)).tolist()[:8],
+                  "model rank diffs", len(bad), bad[:6].tolist(), "seed", int(seeds[0]),
+                  [(float(m.rank[i]).hex(), float(r[i]).hex()) for i in bad[:3]], flush=True)
+            sys.exit(1)
+    runs += 1
+print(f"soak ok: {runs} random graphs, fold == scan == C restatement bit for bit")
