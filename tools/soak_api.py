@@ -1,0 +1,91 @@
+"""Randomised differential soak of the whole C-ABI surface against the C restatement: graphs in the loader's shape
+(users / items / ETC users; LIKE, FRIENDSHIP, AUTHORSHIP, MENTION links, relabelled UNDEFINED links, multi-edges), random
+batches (duplicates, dangling seeds), top-n from 1 to beyond the radix-select limit, full lists, the evaluation entry,
+incremental rebuilds, FAST mode within 1e-6.    python tools/soak_api.py [seconds]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from recommendersystems_amd.rwr_based import Graph, Model, Recommender
+from oracle.c_oracle import FlatGraph, evaluate
+from tests import graphgen as gg
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+t_end = time.time() + budget
+base = int(os.environ.get("SOAK_SEED", "777"))
+first = int(os.environ.get("SOAK_FIRST", "0"))
+runs = 0
+
+
+def fail(case, what, **kw):
+    print("MISMATCH case", case, what, kw, flush=True)
+    sys.exit(1)
+
+
+def b(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+while time.time() < t_end:
+    case = first + runs
+    rng = np.random.default_rng(base + case)
+    nu, ni = int(rng.integers(2, 1500)), int(rng.integers(1, 4000))
+    params = dict(seed=int(rng.integers(0, 2 ** 31)), n_users=nu, n_items=ni, n_likes=int(rng.integers(0, 6 * (nu + ni))),
+                  n_etc=int(rng.choice([0, 0, 7, 60])), p_undefined=float(rng.choice([0.0, 0.05, 0.4])),
+                  n_friend=int(rng.integers(0, 2 * nu)), n_mention=int(rng.integers(0, nu)), n_author=int(rng.integers(0, nu)))
+    g = gg.random_graph(**params)
+    n = len(g["node_id"])
+    F = FlatGraph(**g)
+    mode = "fast" if rng.random() < 0.25 else "exact"
+    G = Graph.from_flat(**g, mode=mode, tile_seeds=int(rng.choice([0, 0, 1, 2, 4, 8, 16, 32, 64])),
+                        seed_row_kernel=str(rng.choice(["auto", "fold", "scan"])))
+    G.buildGraph()
+    rec = Recommender(G)
+    d = float(rng.choice([0.15, 0.15, 0.5, 0.9]))
+    T = int(rng.integers(0, 12))
+    K = int(rng.choice([1, 2, 3, 7, 33, 70]))
+    seeds = rng.integers(0, nu, K).astype(np.int32)
+    top_n = int(rng.choice([1, 3, 10, 100, 1024, 1500]))
+    ids, sc, cnt = rec.RecommendationBatch(seeds, d, T, top_n)
+    oi, os_, oc = F.recommend_batch(seeds, d, T, top_n)
+    if not ((cnt == oc).all()):
+        fail(case, "batch counts", params=params, mode=mode)
+    if mode == "exact":
+        if not ((ids == oi).all() and (b(sc) == b(os_)).all()):
+            fail(case, "batch exact", params=params, K=K, T=T, top_n=top_n, d=d, st=G.stats())
+    else:
+        if np.abs(sc - os_).max(initial=0.0) > 1e-6:
+            fail(case, "batch fast tolerance", params=params, err=float(np.abs(sc - os_).max()))
+    sd = int(seeds[0])
+    full = rec.Recommendation(sd, d, T)
+    fi, fs = F.recommend(sd, d, T)
+    if len(full) != len(fi) or (mode == "exact" and ([x[0] for x in full] != fi.tolist() or not (b([x[1] for x in full]) == b(fs)).all())):
+        fail(case, "full list", params=params, sd=sd, T=T, d=d, mode=mode)
+    if mode == "exact":
+        test = set(int(x) for x in rng.choice(g["node_id"], size=min(n, 20), replace=False))
+        hits, sp, ln = rec.RecommendationEval(sd, d, T, test)
+        eh, esp = evaluate(fi, sorted(test))
+        if (hits, ln) != (eh, len(fi)) or b([sp])[0] != b([esp])[0]:
+            fail(case, "eval", params=params, got=(hits, sp, ln), want=(eh, esp, len(fi)))
+        m = Model(G, float(np.float32(d)), sd); m.run(T)
+        r, _ = F.model_run(float(np.float32(d)), sd, 0, T)
+        if not (b(m.rank) == b(r)).all():
+            fail(case, "model run", params=params, sd=sd, T=T)
+        # incremental rebuild: relabel / reweight a few links, compare with a restatement built from the patched lists
+        mlinks = len(g["dst"])
+        if mlinks:
+            k = int(rng.integers(1, min(mlinks, 50) + 1))
+            idx = np.unique(rng.integers(0, mlinks, k)).astype(np.int64)
+            et = g["etype"].copy(); w = g["w"].copy()
+            et[idx] = rng.choice([0, 1, 2, 5], len(idx)); w[idx] = rng.choice([1.0, 0.5, 3.0], len(idx))
+            G.updateLinks(idx, etype=et[idx], w=w[idx])
+            F2 = FlatGraph(**dict(g, etype=et, w=w))
+            ids, sc, cnt = rec.RecommendationBatch(seeds, d, T, top_n)
+            oi, os_, oc = F2.recommend_batch(seeds, d, T, top_n)
+            if not ((cnt == oc).all() and (ids == oi).all() and (b(sc) == b(os_)).all()):
+                fail(case, "after update_links", params=params, nidx=len(idx))
+    G.close()
+    runs += 1
+print(f"soak ok: {runs} random cases (batch, full list, eval, model, incremental rebuild; exact bitwise, fast within 1e-6)")
