@@ -33,14 +33,15 @@ while time.time() < t_end:
     g = dict(node_id=rng.permutation(n).astype(np.int64), node_type=np.array([1] * U + [2] * I, dtype=np.uint8),
              rowptr=rowptr, dst=dst.astype(np.int32), etype=et, w=w.astype(np.float64))
     F = FlatGraph(**g)
-    K = int(rng.choice([1, 2, 5, 16, 40]))
+    K = int(rng.choice([1, 2, 5, 16, 40, 130, 300]))
     seeds = rng.integers(0, U, K).astype(np.int32)
     T = int(rng.integers(1, 12)); d = float(rng.choice([0.15, 0.5, 0.01, 0.85]))
-    oi, os_, oc = F.recommend_batch(seeds, d, T, 20)
+    top_n = int(rng.choice([1, 20, 20, 300, 1100]))
+    oi, os_, oc = F.recommend_batch(seeds, d, T, top_n)
     for kern in ("scan", "fold"):
         G = Graph.from_flat(**g, seed_row_kernel=kern, tile_seeds=int(rng.choice([0, 1, 8, 32])) if K > 1 else 0)
         G.buildGraph()
-        ids, sc, cnt = Recommender(G).RecommendationBatch(seeds, d, T, 20)
+        ids, sc, cnt = Recommender(G).RecommendationBatch(seeds, d, T, top_n)
         ok_b = bool((cnt == oc).all() and (ids == oi).all() and (sc.view(np.uint64) == os_.view(np.uint64)).all())
         m = Model(G, float(np.float32(d)), int(seeds[0])); m.run(T)
         r, _ = F.model_run(float(np.float32(d)), int(seeds[0]), 0, T)
