@@ -38,10 +38,14 @@ namespace rwr {
 
 // rank-matrix elements per block (rows x G).  A single seed gets 1024-row blocks: a block that crosses a binade is
 // redone row by row by ONE wave, and that serial redo, not the parallel passes, is what a single-seed step waits for.
+// Wide tiles (G >= 16) get 16384-element blocks, walked by k_cs_block as four 4096-element pieces: the per-seed carry is a
+// serial walk over the blocks, and at 32 seeds per row a 4096-element block is only 128 rows.
 template <int G> struct CsGeom {
-    static constexpr int E = (G == 1) ? 1024 : 4096;
-    static constexpr int R = E / 256;          // rows per thread run of k_cs_block
-    static constexpr int CH = E / G;           // rows per block
+    static constexpr int EP = (G == 1) ? 1024 : 4096;   // elements per LDS piece of k_cs_block
+    static constexpr int P = (G >= 16) ? 4 : 1;         // pieces per block
+    static constexpr int E = EP * P;                    // elements per block = per (d0, d1) cell
+    static constexpr int R = EP / 256;                  // rows per thread run inside a piece
+    static constexpr int CH = E / G;                    // rows per block
 };
 constexpr unsigned long long CS_HID = 1ull << 52;
 constexpr unsigned long long CS_FRAC = CS_HID - 1ull;
@@ -107,9 +111,10 @@ __global__ __launch_bounds__(256) void k_cs_links(int nchunks, int CH, const int
     lnk[(size_t)slot * (size_t)(nchunks + 1) + c] = out;
 }
 
-// One workgroup per (block of E elements, tile).  The block's restart addends are staged in LDS (coalesced
-// loads); thread (rl, k) then walks its run of R consecutive rows of seed k in row order, taking a row's links
-// into the seed before the row's restart addend; the runs are combined in row order by an LDS tree.
+// One workgroup per (block of E elements, tile), walked as P pieces of EP elements.  A piece's restart addends are
+// staged in LDS (coalesced loads); thread (rl, k) then walks its run of R consecutive rows of seed k in row order, taking
+// a row's links into the seed before the row's restart addend; the runs are combined in row order by an LDS tree and the
+// pieces are composed in order.
 template <int G, bool FUNCS>
 __global__ __launch_bounds__(256) void k_cs_block(int32_t n, int nchunks, const uint8_t *__restrict__ dangling,
                                                   const double *__restrict__ X, const int32_t *__restrict__ seeds,
@@ -120,88 +125,99 @@ __global__ __launch_bounds__(256) void k_cs_block(int32_t n, int nchunks, const 
                                                   double *__restrict__ approx, long long *__restrict__ od0,
                                                   long long *__restrict__ od1)
 {
-    constexpr int CS_E = CsGeom<G>::E, CS_R = CsGeom<G>::R;
-    constexpr int CH = CS_E / G, RL = 256 / G;
-    static_assert(CH == RL * CS_R, "run length");
-    __shared__ double a_s[CS_E + CS_E / 16];
+    constexpr int EP = CsGeom<G>::EP, NP = CsGeom<G>::P, CS_R = CsGeom<G>::R;
+    constexpr int CHP = EP / G, CH = CsGeom<G>::CH, RL = 256 / G;     // rows per piece / per block; row lanes
+    static_assert(CHP == RL * CS_R, "run length");
+    __shared__ double a_s[EP + EP / 16];
     __shared__ long long r0[256], r1[256];
     const int c = blockIdx.x, tile = blockIdx.y, tid = threadIdx.x;
     const double *x = X + (size_t)tile * (size_t)n * G;
-    const int64_t row0 = (int64_t)c * CH, el0 = row0 * G, total = (int64_t)n * G;
-#pragma unroll
-    for (int j = 0; j < CS_E / 256; ++j) {
-        const int q = tid + 256 * j;
-        const int64_t el = el0 + q;
-        double a = 0.0;
-        if (el < total) {
-            const double xv = x[el];
-            const double rw = c1 * xv;                       // Model.cs:84
-            a = dangling[el / G] ? xv : (xv - rw);           // Model.cs:97 / :91
-        }
-        a_s[cs_pad(q)] = a;
-    }
-    __syncthreads();
+    const int64_t total = (int64_t)n * G;
     const int k = tid % G, rl = tid / G;
     const int slot = tile * G + k;
     const int32_t s = seeds[slot];
-    const int64_t ra = row0 + (int64_t)rl * CS_R;
-    int32_t l = 0, l1 = 0;
+    // this block's share of the seed's in-link list (sorted by source row)
+    int32_t l1 = 0, a0 = 0;
     const int32_t *srcp = in_src;
     const double *termp = evterm;
     if (s >= 0) {
         const int32_t *lk = lnk + (size_t)slot * (size_t)(nchunks + 1) + c;
-        const int32_t a0 = lk[0], a1 = lk[1];
-        if (a1 > a0) {
-            srcp = in_src + in_ptr[s];
-            termp = evterm + evoff[slot];
-            int32_t lo = a0, hi = a1;
+        a0 = lk[0];
+        l1 = lk[1];
+        if (l1 > a0) { srcp = in_src + in_ptr[s]; termp = evterm + evoff[slot]; }
+    }
+    const size_t oidx = (size_t)slot * nchunks + c;
+    const int eb = FUNCS ? e_pred[oidx] : 0;
+    PF ftot{0, 0};
+    double atot = 0.0;
+    for (int piece = 0; piece < NP; ++piece) {
+        const int64_t row0 = (int64_t)c * CH + (int64_t)piece * CHP, el0 = row0 * G;
+        if (piece) __syncthreads();                          // the previous piece's LDS reads are done
+#pragma unroll
+        for (int j = 0; j < EP / 256; ++j) {
+            const int q = tid + 256 * j;
+            const int64_t el = el0 + q;
+            double a = 0.0;
+            if (el < total) {
+                const double xv = x[el];
+                const double rw = c1 * xv;                       // Model.cs:84
+                a = dangling[el / G] ? xv : (xv - rw);           // Model.cs:97 / :91
+            }
+            a_s[cs_pad(q)] = a;
+        }
+        __syncthreads();
+        const int64_t ra = row0 + (int64_t)rl * CS_R;
+        int32_t l = l1;
+        if (l1 > a0) {                                           // first link whose source row is >= this run's first row
+            int32_t lo = a0, hi = l1;
             while (lo < hi) {
                 const int32_t mid = lo + ((hi - lo) >> 1);
                 if ((int64_t)srcp[mid] < ra) lo = mid + 1; else hi = mid;
             }
             l = lo;
-            l1 = a1;
+        }
+        if constexpr (FUNCS) {
+            PF f{0, 0};
+#pragma unroll
+            for (int u = 0; u < CS_R; ++u) {
+                const int64_t row = ra + u;
+                while (l < l1 && (int64_t)srcp[l] == row) { f = pf_compose(f, pf_of(termp[l], eb)); ++l; }   // Model.cs:85-88
+                f = pf_compose(f, pf_of(a_s[cs_pad((rl * CS_R + u) * G + k)], eb));                        // Model.cs:91-93,96-97
+            }
+            r0[tid] = f.d0;
+            r1[tid] = f.d1;
+            __syncthreads();
+            for (int st = 1; st < RL; st <<= 1) {
+                if ((rl & (2 * st - 1)) == 0 && rl + st < RL) {
+                    PF a{r0[tid], r1[tid]}, b{r0[tid + st * G], r1[tid + st * G]};
+                    const PF r = pf_compose(a, b);
+                    r0[tid] = r.d0;
+                    r1[tid] = r.d1;
+                }
+                __syncthreads();
+            }
+            if (rl == 0) ftot = pf_compose(ftot, PF{r0[tid], r1[tid]});   // pieces in row order
+        } else {
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < CS_R; ++u) {
+                const int64_t row = ra + u;
+                while (l < l1 && (int64_t)srcp[l] == row) { acc += termp[l]; ++l; }
+                acc += a_s[cs_pad((rl * CS_R + u) * G + k)];
+            }
+            double *racc = reinterpret_cast<double *>(r0);
+            racc[tid] = acc;
+            __syncthreads();
+            for (int st = 1; st < RL; st <<= 1) {
+                if ((rl & (2 * st - 1)) == 0 && rl + st < RL) racc[tid] += racc[tid + st * G];
+                __syncthreads();
+            }
+            if (rl == 0) atot += racc[tid];
         }
     }
-    const size_t oidx = (size_t)slot * nchunks + c;
-    if constexpr (FUNCS) {
-        const int eb = e_pred[oidx];
-        PF f{0, 0};
-#pragma unroll
-        for (int u = 0; u < CS_R; ++u) {
-            const int64_t row = ra + u;
-            while (l < l1 && (int64_t)srcp[l] == row) { f = pf_compose(f, pf_of(termp[l], eb)); ++l; }   // Model.cs:85-88
-            f = pf_compose(f, pf_of(a_s[cs_pad((rl * CS_R + u) * G + k)], eb));                        // Model.cs:91-93,96-97
-        }
-        r0[tid] = f.d0;
-        r1[tid] = f.d1;
-        __syncthreads();
-        for (int st = 1; st < RL; st <<= 1) {
-            if ((rl & (2 * st - 1)) == 0 && rl + st < RL) {
-                PF a{r0[tid], r1[tid]}, b{r0[tid + st * G], r1[tid + st * G]};
-                const PF r = pf_compose(a, b);
-                r0[tid] = r.d0;
-                r1[tid] = r.d1;
-            }
-            __syncthreads();
-        }
-        if (rl == 0) { od0[oidx] = r0[tid]; od1[oidx] = r1[tid]; }
-    } else {
-        double acc = 0.0;
-#pragma unroll
-        for (int u = 0; u < CS_R; ++u) {
-            const int64_t row = ra + u;
-            while (l < l1 && (int64_t)srcp[l] == row) { acc += termp[l]; ++l; }
-            acc += a_s[cs_pad((rl * CS_R + u) * G + k)];
-        }
-        double *racc = reinterpret_cast<double *>(r0);
-        racc[tid] = acc;
-        __syncthreads();
-        for (int st = 1; st < RL; st <<= 1) {
-            if ((rl & (2 * st - 1)) == 0 && rl + st < RL) racc[tid] += racc[tid + st * G];
-            __syncthreads();
-        }
-        if (rl == 0) approx[oidx] = racc[tid];
+    if (rl == 0) {
+        if constexpr (FUNCS) { od0[oidx] = ftot.d0; od1[oidx] = ftot.d1; }
+        else approx[oidx] = atot;
     }
 }
 
@@ -434,7 +450,7 @@ __global__ __launch_bounds__(64) void k_cs_carry(int32_t n, int nchunks, const u
 
 // ---------------------------------------------------------------------------------------------- host side
 
-static inline int cs_block_elems(int G) { return G == 1 ? CsGeom<1>::E : CsGeom<2>::E; }
+static inline int cs_block_elems(int G) { return G == 1 ? CsGeom<1>::E : (G >= 16 ? CsGeom<16>::E : CsGeom<2>::E); }
 static inline int cs_nchunks(int32_t n, int G) { return (int)(((int64_t)n * G + cs_block_elems(G) - 1) / cs_block_elems(G)); }
 
 #define CS_DISPATCH_G(G, CALL)                            \
