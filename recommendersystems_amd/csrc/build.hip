@@ -95,6 +95,19 @@ __global__ __launch_bounds__(256) void k_order_keys(int32_t n, const int64_t *__
     atomicMax(maxdeg, (int)deg);
 }
 
+// single-seed SpMV order: phase (ITEM rows first) then in-degree descending
+__global__ __launch_bounds__(256) void k_order_keys_phase(int32_t n, const int64_t *__restrict__ in_ptr,
+                                                          const uint8_t *__restrict__ node_type,
+                                                          uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval)
+{
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t deg = (uint32_t)(in_ptr[i + 1] - in_ptr[i]);
+    const uint32_t phase = node_type[i] == RWR_NODE_ITEM ? 0u : 1u;
+    dkey[i] = (phase << 31) | (0x7FFFFFFFu - (deg & 0x7FFFFFFFu));
+    dval[i] = (uint32_t)i;
+}
+
 // items by id descending: ascending sort of ~orderable(id) over the ITEM rows only (every 64-bit key value is a
 // legitimate id -- INT64_MIN maps to ~0 -- so non-items cannot be parked behind a sentinel key)
 __global__ void k_item_id_keys(int32_t n_items, const int32_t *__restrict__ item_rows, const int64_t *__restrict__ node_id,
@@ -171,6 +184,9 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     RWR_TRY(g->w_src.alloc(n));
     RWR_TRY(g->in_ptr.alloc((size_t)n + 1));
     RWR_TRY(g->row_order.alloc(n));
+    RWR_TRY(g->row_order_x.alloc(n));
+    g->h_is_item.assign((size_t)n, 0);
+    for (int32_t i = 0; i < n; ++i) g->h_is_item[i] = node_type[i] == RWR_NODE_ITEM;
     RWR_TRY(g->item_order.alloc(n_items));
     RWR_TRY(g->item_rows.alloc(n_items));
 
@@ -296,6 +312,10 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, 32, temp.p, s, &alt));
     hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p, g->row_order.p,
                        (int64_t)n);
+    hipLaunchKernelGGL(k_order_keys_phase, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->in_ptr.p, g->node_type.p, skey.p, sval.p);
+    RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, 32, temp.p, s, &alt));
+    hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p, g->row_order_x.p,
+                       (int64_t)n);
     if (first) {   // (the node arrays never change: an incremental rebuild keeps both item orders)
         // ITEM rows in ascending row order: one stable pass on the flag (item ? 0 : 1)
         hipLaunchKernelGGL(k_item_flag_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->node_type.p, skey.p, sval.p);
@@ -321,12 +341,18 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     g->h_dangling.resize((size_t)n);
     RWR_HIP(hipMemcpy(g->h_dangling.data(), g->dangling.p, (size_t)n, hipMemcpyDeviceToHost));
     g->bin_end[0] = g->bin_end[1] = g->bin_end[2] = g->bin_huge = 0;
+    for (int ph = 0; ph < 2; ++ph) g->x_rows[ph] = g->x_bins[ph][0] = g->x_bins[ph][1] = g->x_bins[ph][2] = 0;
     for (int32_t i = 0; i < n; ++i) {
         const int64_t deg = g->h_in_ptr[i + 1] - g->h_in_ptr[i];
         g->bin_huge += deg >= 2048;
         g->bin_end[0] += deg >= 128;
         g->bin_end[1] += deg >= 32;
         g->bin_end[2] += deg >= 4;
+        const int ph = g->h_is_item[i] ? 0 : 1;
+        g->x_rows[ph] += 1;
+        g->x_bins[ph][0] += deg >= 128;
+        g->x_bins[ph][1] += deg >= 32;
+        g->x_bins[ph][2] += deg >= 4;
     }
     float ms = 0.f;
     RWR_HIP(hipEventElapsedTime(&ms, e0, e1));

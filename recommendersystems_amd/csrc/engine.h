@@ -38,6 +38,13 @@ struct rwr_graph {
     rwr::DevBuf<double> w_src;        // uniform graphs: the one normalised weight of source i
     rwr::DevBuf<uint8_t> dangling;    // graph[i] == null (Graph.cs:53,86)
     rwr::DevBuf<int32_t> row_order;   // destination rows by in-degree descending (stable)
+    // single-seed SpMV: ITEM rows first, then the rest, each by in-degree descending.  An item's in-links come from users and
+    // a user's mostly from items, so each phase gathers from one region of the rank vector and the XCDs' L2s are not split
+    // between the two regions; x_rows[p] = rows of phase p, x_bins[p][0..2] = how many of them have >= 128 / 32 / 4 in-links
+    rwr::DevBuf<int32_t> row_order_x;
+    int32_t x_rows[2] = {0, 0};
+    int32_t x_bins[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    std::vector<uint8_t> h_is_item;
     rwr::DevBuf<int32_t> item_order;  // ITEM rows by id descending
     rwr::DevBuf<int32_t> item_rows;   // ITEM rows by row index ascending
 

@@ -82,7 +82,7 @@ __device__ __forceinline__ double readlane_f64(double v, int t)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), t);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ void spmv_exact_wave(int bid, int nblk, int32_t r1, const int64_t *__restrict__ in_ptr,
+__device__ __forceinline__ void spmv_exact_wave(int bid, int nblk, int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
                                                 const int32_t *__restrict__ in_src, const double *__restrict__ in_w,
                                                 const int32_t *__restrict__ row_order, const double *__restrict__ x,
                                                 double *__restrict__ y, int32_t my_seed, double c1,
@@ -96,7 +96,7 @@ __device__ __forceinline__ void spmv_exact_wave(int bid, int nblk, int32_t r1, c
     double(*pb)[WAVE] = prod_s[threadIdx.x / WAVE];
     const int64_t nwaves = ((int64_t)nblk * blockDim.x) / WAVE;
     int buf = 0;
-    int64_t r = ((int64_t)bid * blockDim.x + threadIdx.x) / WAVE;
+    int64_t r = (int64_t)r0 + ((int64_t)bid * blockDim.x + threadIdx.x) / WAVE;
     int32_t j = -1;
     int64_t p = 0, e = 0;
     if (r < r1) { j = row_order[r]; p = in_ptr[j]; e = in_ptr[j + 1]; }
@@ -195,10 +195,10 @@ __device__ __forceinline__ void spmv_exact_group(int bid, int nblk, int32_t r0, 
     }
 }
 
-// rows [0, b0): a wave per row; [b0, b1): 16 lanes per row; [b1, b2): 4 lanes per row; [b2, n): a lane per row.
+// rows [ra, b0): a wave per row; [b0, b1): 16 lanes per row; [b1, b2): 4 lanes per row; [b2, n): a lane per row.
 // Workgroups [0, nb0) serve the first bin, the next nb1 the second, ...
-__global__ __launch_bounds__(256) void k_spmv_exact_binned(int nb0, int nb1, int nb2, int nb3, int32_t b0, int32_t b1, int32_t b2,
-                                                           int32_t n, const int64_t *__restrict__ in_ptr,
+__global__ __launch_bounds__(256) void k_spmv_exact_binned(int nb0, int nb1, int nb2, int nb3, int32_t ra, int32_t b0, int32_t b1,
+                                                           int32_t b2, int32_t n, const int64_t *__restrict__ in_ptr,
                                                            const int32_t *__restrict__ in_src,
                                                            const double *__restrict__ in_w,
                                                            const int32_t *__restrict__ row_order,
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_spmv_exact_binned(int nb0, int nb1, int
 {
     const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
     int b = blockIdx.x;
-    if (b < nb0) { spmv_exact_wave(b, nb0, b0, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out); return; }
+    if (b < nb0) { spmv_exact_wave(b, nb0, ra, b0, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out); return; }
     b -= nb0;
     if (b < nb1) { spmv_exact_group<16>(b, nb1, b0, b1, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out); return; }
     b -= nb1;
@@ -302,22 +302,37 @@ void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hip
     if (n > b2) hipLaunchKernelGGL(k_spmv_vector<1>, dim3(grid(n - b2, 1)), dim3(256), 0, s, b2, n, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, x, y, c1);
 }
 
-// EXACT single seed: rows binned by in-degree (row_order is sorted by it unless RWR_ROW_ORDER says otherwise)
+// EXACT single seed: two phases (ITEM rows, then the others -- engine.h: row_order_x), each binned by in-degree:
+// >= 128 in-links a wave per row; >= 32: 16 lanes per row; >= 4: 4 lanes per row; below: a lane per row
+// (RWR_GROUP_ROWS = 0 keeps everything under 128 on the lane-per-row form; RWR_ROW_ORDER != 0 or RWR_SPMV_PHASES = 0: one
+// pass in row_order).  One launch per phase.
 void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *seeds, double c1, int skip,
                        const uint32_t *act, uint32_t *nz_out, hipStream_t s)
 {
     static const bool by_degree = [] { const char *e = getenv("RWR_ROW_ORDER"); return !e || atoi(e) == 0; }();
-    // in-degree >= 128: a wave per row; >= 32: 16 lanes per row; >= 4: 4 lanes per row; below: a lane per row
-    // (RWR_GROUP_ROWS = 0 keeps everything under 128 on the lane-per-row form); one launch for all bins
     static const int group_rows = [] { const char *e = getenv("RWR_GROUP_ROWS"); return e ? atoi(e) : 2; }();
-    const int32_t b0 = by_degree ? g->bin_end[0] : 0;
-    const int32_t b1 = (by_degree && group_rows >= 1) ? g->bin_end[1] : b0;
-    const int32_t b2 = (by_degree && group_rows >= 2) ? g->bin_end[2] : b1;
+    // two phases pay once the rank vector no longer fits the L2s (measured: -17 % SpMV time on the 6 M-node graph, nothing on
+    // the 0.6 M-node one, +10 % on the dense 0.2 M-node one, where the second launch only adds a tail)
+    static const int phases_env = [] { const char *e = getenv("RWR_SPMV_PHASES"); return e ? atoi(e) : -1; }();
+    const int phases = phases_env >= 0 ? phases_env : (g->n >= 2000000 ? 1 : 0);
     auto blocks_for = [](int64_t rows, int W) { const int64_t b = (rows * W + 255) / 256; return (int)(b < 0 ? 0 : (b > 16384 ? 16384 : b)); };
-    const int nb0 = blocks_for(b0, 64), nb1 = blocks_for(b1 - b0, 16), nb2 = blocks_for(b2 - b1, 4), nb3 = blocks_for(g->n - b2, 1);
-    if (nb0 + nb1 + nb2 + nb3 > 0)
-        hipLaunchKernelGGL(k_spmv_exact_binned, dim3((unsigned)(nb0 + nb1 + nb2 + nb3)), dim3(256), 0, s, nb0, nb1, nb2, nb3, b0,
-                           b1, b2, g->n, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, act, nz_out);
+    auto launch = [&](const int32_t *order, int32_t ra, int32_t rows, const int32_t bins[3]) {
+        if (rows <= 0) return;
+        const int32_t b0 = ra + (by_degree ? bins[0] : 0);
+        const int32_t b1 = (by_degree && group_rows >= 1) ? ra + bins[1] : b0;
+        const int32_t b2 = (by_degree && group_rows >= 2) ? ra + bins[2] : b1;
+        const int32_t rend = ra + rows;
+        const int nb0 = blocks_for(b0 - ra, 64), nb1 = blocks_for(b1 - b0, 16), nb2 = blocks_for(b2 - b1, 4), nb3 = blocks_for(rend - b2, 1);
+        if (nb0 + nb1 + nb2 + nb3 > 0)
+            hipLaunchKernelGGL(k_spmv_exact_binned, dim3((unsigned)(nb0 + nb1 + nb2 + nb3)), dim3(256), 0, s, nb0, nb1, nb2, nb3, ra, b0,
+                               b1, b2, rend, g->in_ptr.p, g->in_src.p, g->in_w.p, order, X, Y, seeds, c1, skip, act, nz_out);
+    };
+    if (by_degree && phases) {
+        launch(g->row_order_x.p, 0, g->x_rows[0], g->x_bins[0]);
+        launch(g->row_order_x.p, g->x_rows[0], g->x_rows[1], g->x_bins[1]);
+    } else {
+        launch(g->row_order.p, 0, g->n, g->bin_end);
+    }
 }
 
 }  // namespace rwr
