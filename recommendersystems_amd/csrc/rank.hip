@@ -314,6 +314,66 @@ __global__ __launch_bounds__(256) void k_sel_sort_emit(const int32_t *__restrict
     }
 }
 
+// Few items (an ego network: n_items <= SEL_SLOTS): the whole ranked list of a seed is one workgroup's bitonic sort in
+// LDS on the 128-bit key (score, id) -- one launch instead of the ~27 of the segmented radix sort.  One block per seed
+// slot of the tile; candidates = ITEM rows whose score is not the exclusion marker (Recommender.cs:27-31).
+template <int G>
+__global__ __launch_bounds__(256) void k_rank_small(int32_t n_items, const int32_t *__restrict__ item_rows,
+                                                    const int64_t *__restrict__ node_id, const double *__restrict__ X,
+                                                    const int32_t *__restrict__ seeds, const int32_t *__restrict__ slot_k,
+                                                    int32_t top_n, int64_t *__restrict__ out_id,
+                                                    double *__restrict__ out_score, int32_t *__restrict__ out_counts)
+{
+    extern __shared__ SelCand sc[];
+    __shared__ int cnt_s;
+    const int k = blockIdx.x;
+    const int32_t orow = slot_k[k];
+    if (orow < 0 || seeds[k] < 0) return;
+    int N2 = 1;
+    while (N2 < n_items) N2 <<= 1;
+    if (threadIdx.x == 0) cnt_s = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < N2; i += blockDim.x) {
+        SelCand c{0ull, 0ull};                                   // below every real key: non-candidates sink to the end
+        if (i < n_items) {
+            const int32_t row = item_rows[i];
+            const double sv = X[(size_t)row * G + k];
+            if (sv >= 0.0) { c.hi = f64_orderable(sv); c.lo = i64_orderable(node_id[row]); ++mine; }
+        }
+        sc[i] = c;
+    }
+    if (mine) atomicAdd(&cnt_s, mine);
+    __syncthreads();
+    for (int size = 2; size <= N2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < N2 / 2; t += blockDim.x) {
+                const int lo_i = 2 * t - (t & (stride - 1));
+                const int hi_i = lo_i + stride;
+                const bool desc = (lo_i & size) == 0;
+                const SelCand a = sc[lo_i], b = sc[hi_i];
+                const bool a_lt_b = (a.hi < b.hi) || (a.hi == b.hi && a.lo < b.lo);
+                if (a_lt_b == desc) {
+                    sc[lo_i] = b;
+                    sc[hi_i] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int cnt = cnt_s;
+    const int take = cnt < top_n ? cnt : top_n;
+    if (threadIdx.x == 0) out_counts[orow] = take;
+    for (int i = threadIdx.x; i < take; i += blockDim.x) {
+        const SelCand v = sc[i];
+        out_id[(size_t)orow * top_n + i] = (int64_t)(v.lo ^ 0x8000000000000000ull);
+        const uint64_t u = (v.hi & 0x8000000000000000ull) ? (v.hi ^ 0x8000000000000000ull) : ~v.hi;
+        double sv;
+        __builtin_memcpy(&sv, &u, 8);
+        out_score[(size_t)orow * top_n + i] = sv;
+    }
+}
+
 #define RWR_DISPATCH_G(G, CALL)                          \
     switch (G) {                                         \
         case 1: { constexpr int GG = 1; CALL; } break;   \
@@ -330,6 +390,18 @@ int32_t rank_tile(rwr_graph *g, int G, const int32_t *d_slot_k_tile, int32_t top
 {
     const int32_t m = g->n_items;
     if (m == 0) return RWR_OK;
+    if (m <= SEL_SLOTS) {
+        int N2 = 1;
+        while (N2 < m) N2 <<= 1;
+        RWR_DISPATCH_G(G, {
+            (void)hipFuncSetAttribute((const void *)k_rank_small<GG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      SEL_SLOTS * (int)sizeof(SelCand));
+            hipLaunchKernelGGL(k_rank_small<GG>, dim3((unsigned)G), dim3(256), (size_t)N2 * sizeof(SelCand), s, m, g->item_rows.p,
+                               g->node_id.p, X, d_seeds_tile, d_slot_k_tile, top_n, g->d_out_id.p, g->d_out_score.p, g->d_counts.p);
+        });
+        RWR_HIP(hipGetLastError());
+        return RWR_OK;
+    }
     const size_t tot = (size_t)G * m;
     RWR_TRY(g->keys.ensure(tot));
     RWR_TRY(g->keys_alt.ensure(tot));
