@@ -485,28 +485,60 @@ int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, 
 }
 
 // one step's seed-row chain for a tile group (the link terms d_evterm must already be on the stream)
+static int32_t chain_scan_launch(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,
+                                 const int64_t *d_evoff, double c1, uint32_t *nz_out, const int32_t *lnk, hipStream_t s);
+
 int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,
                         const int64_t *d_evoff, double c1, uint32_t *nz_out, hipStream_t s)
+{
+    return chain_scan_launch(g, G, tg, X, Y, d_seeds, d_evoff, c1, nz_out, g->cs_lnk.p, s);
+}
+
+// The reference's checkConvergence (Model.cs:110-115) is the same kind of chain: diff += |rank[i] - nextRank[i]| over
+// all nodes in order, non-negative addends.  The scan machinery reproduces that sequential fp64 sum bit for bit:
+// D holds the addends; with (1-d) := 0 a row's addend is D[i] - 0*D[i] = D[i], the link table is all zero (no in-link
+// terms) and the "seed" slot 0 only names where the sum is written (*out).
+int32_t chain_scan_sum(rwr_graph *g, const double *D, double *out, hipStream_t s)
+{
+    const int nchunks = cs_nchunks(g->n, 1);
+    const size_t cells = (size_t)nchunks;
+    RWR_TRY(g->cs_approx.ensure(cells));
+    RWR_TRY(g->cs_e.ensure(cells));
+    RWR_TRY(g->cs_d0.ensure(cells));
+    RWR_TRY(g->cs_d1.ensure(cells));
+    RWR_TRY(g->cs_lnk0.ensure((size_t)nchunks + 2));
+    if (!g->cs_redo.p) {
+        RWR_TRY(g->cs_redo.alloc(1));
+        RWR_HIP(hipMemsetAsync(g->cs_redo.p, 0, sizeof(unsigned long long), s));
+    }
+    // words [0, nchunks]: the all-zero link table; word nchunks + 1: the slot's "seed" (node 0)
+    RWR_HIP(hipMemsetAsync(g->cs_lnk0.p, 0, ((size_t)nchunks + 2) * sizeof(int32_t), s));
+    RWR_TRY(g->d_evoff.ensure(2));
+    return chain_scan_launch(g, 1, 1, D, out, g->cs_lnk0.p + nchunks + 1, g->d_evoff.p, 0.0, nullptr, g->cs_lnk0.p, s);
+}
+
+static int32_t chain_scan_launch(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,
+                                 const int64_t *d_evoff, double c1, uint32_t *nz_out, const int32_t *lnk, hipStream_t s)
 {
     const int nchunks = cs_nchunks(g->n, G);
     const dim3 grid((unsigned)nchunks, (unsigned)tg);
     static const int direct_max = [] { const char *e = getenv("RWR_SCAN_DIRECT_BLOCKS"); return e ? atoi(e) : 8; }();
     if (nchunks <= direct_max) {
         CS_DISPATCH_G(G, hipLaunchKernelGGL(k_cs_carry<GG>, dim3((unsigned)(tg * G)), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y,
-                                            d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, g->cs_lnk.p,
+                                            d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, lnk,
                                             g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, nz_out, g->cs_redo.p, 1));
         RWR_HIP(hipGetLastError());
         return RWR_OK;
     }
     CS_DISPATCH_G(G, hipLaunchKernelGGL((k_cs_block<GG, false>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X,
-                                        d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, g->cs_lnk.p,
+                                        d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, lnk,
                                         (const int32_t *)nullptr, g->cs_approx.p, (long long *)nullptr, (long long *)nullptr));
     hipLaunchKernelGGL(k_cs_plan, dim3((unsigned)(tg * G)), dim3(64), 0, s, nchunks, d_seeds, g->cs_approx.p, g->cs_e.p);
     CS_DISPATCH_G(G, hipLaunchKernelGGL((k_cs_block<GG, true>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X,
-                                        d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, g->cs_lnk.p,
+                                        d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, lnk,
                                         g->cs_e.p, (double *)nullptr, g->cs_d0.p, g->cs_d1.p));
     CS_DISPATCH_G(G, hipLaunchKernelGGL(k_cs_carry<GG>, dim3((unsigned)(tg * G)), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y,
-                                        d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, g->cs_lnk.p,
+                                        d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, lnk,
                                         g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, nz_out, g->cs_redo.p, 0));
     RWR_HIP(hipGetLastError());
     return RWR_OK;

@@ -63,6 +63,8 @@ struct rwr_graph {
     rwr::DevBuf<int32_t> cs_e;
     rwr::DevBuf<long long> cs_d0, cs_d1;
     rwr::DevBuf<int32_t> cs_lnk;
+    rwr::DevBuf<int32_t> cs_lnk0;     // all-zero link table + slot for chain_scan_sum (checkConvergence)
+    rwr::DevBuf<double> cs_diff;      // |rank - nextRank| per node (checkConvergence)
     rwr::DevBuf<unsigned long long> cs_redo;   // blocks redone by the carry kernel (binade crossings + mispredictions)
     rwr::DevBuf<uint64_t> keys, keys_alt;
     rwr::DevBuf<uint32_t> vals, vals_alt;
@@ -113,6 +115,7 @@ int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, 
 int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,
                         const int64_t *d_evoff, double c1, uint32_t *nz_out, hipStream_t s);
 int32_t chain_scan_collect(rwr_graph *g, hipStream_t s);
+int32_t chain_scan_sum(rwr_graph *g, const double *D, double *out, hipStream_t s);   // exact sequential sum of n addends >= 0
 
 
 }  // namespace rwr

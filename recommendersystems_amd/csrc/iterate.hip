@@ -1136,6 +1136,12 @@ __global__ __launch_bounds__(256) void k_l1_partial(const double *__restrict__ a
     }
     if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
+__global__ __launch_bounds__(256) void k_absdiff(const double *__restrict__ a, const double *__restrict__ b, int32_t n,
+                                                 double *__restrict__ d)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const double x = a[i], y = b[i]; d[i] = (x > y) ? (x - y) : (y - x); }   // Math.Abs(rank - nextRank), Model.cs:113
+}
 __global__ __launch_bounds__(256) void k_rr_partial(const double *__restrict__ x, const uint8_t *__restrict__ dangling,
                                                     int32_t n, double c1, double *__restrict__ part)
 {
@@ -1205,8 +1211,12 @@ int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double
             RWR_TRY(gi.step(pool, a, b));                                   // deliverRanks + updateRanks
             ++done;
             if (!by_count) {                                                // checkConvergence (Model.cs:58-65)
-                hipLaunchKernelGGL(k_l1_partial, dim3(RED_GRID), dim3(256), 0, s, gi.Y, gi.X, n, part);
-                hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(1), 0, s, part, RED_GRID, scalar);
+                // the reference's sequential sum of |rank[i] - nextRank[i]|, reproduced bit for bit by the binade scan
+                // (d_evterm must exist for the scan's pointer arithmetic even though no link term is read)
+                RWR_TRY(g->cs_diff.ensure((size_t)n));
+                RWR_TRY(g->d_evterm.ensure(1));
+                hipLaunchKernelGGL(k_absdiff, dim3(cdiv((size_t)n, 256)), dim3(256), 0, s, gi.Y, gi.X, n, g->cs_diff.p);
+                RWR_TRY(chain_scan_sum(g, g->cs_diff.p, scalar, s));
                 double diff = 0;
                 RWR_HIP(hipMemcpyAsync(&diff, scalar, sizeof(double), hipMemcpyDeviceToHost, s));
                 RWR_HIP(hipStreamSynchronize(s));

@@ -73,6 +73,21 @@ while time.time() < t_end:
         r, _ = F.model_run(float(np.float32(d)), sd, 0, T)
         if not (b(m.rank) == b(r)).all():
             fail(case, "model run", params=params, sd=sd, T=T)
+        # threshold run (same iteration count, same ranks), one stepwise deliverRanks, global model to tolerance
+        if rng.random() < 0.3:
+            thr = float(rng.choice([1e-2, 1e-6, 1.0]))
+            m2 = Model(G, float(np.float32(d)), sd); m2.run(thr)
+            r2, it2 = F.model_run(float(np.float32(d)), sd, 1, thr)
+            if m2.iterations != it2 or not (b(m2.rank) == b(r2)).all():
+                fail(case, "threshold run", params=params, sd=sd, thr=thr, it=(m2.iterations, it2))
+            m3 = Model(G, float(np.float32(d)), sd); m3.run(2); m3.deliverRanks()
+            r3, _ = F.model_run(float(np.float32(d)), sd, 0, 3)
+            if not (b(m3.nextRank) == b(r3)).all():
+                fail(case, "deliverRanks", params=params, sd=sd)
+            mg = Model(G, float(np.float32(d))); mg.run(4)
+            rg, _ = F.model_run(float(np.float32(d)), -1, 0, 4)
+            if not np.allclose(mg.rank, rg, rtol=1e-11, atol=1e-11):
+                fail(case, "global model", params=params, err=float(np.abs(mg.rank - rg).max()))
         # incremental rebuild: relabel / reweight a few links, compare with a restatement built from the patched lists
         mlinks = len(g["dst"])
         if mlinks:
