@@ -17,6 +17,7 @@ t_end = time.time() + budget
 base = int(os.environ.get("SOAK_SEED", "777"))
 first = int(os.environ.get("SOAK_FIRST", "0"))
 runs = 0
+t_last = time.time()
 
 
 def fail(case, what, **kw):
@@ -103,4 +104,7 @@ while time.time() < t_end:
                 fail(case, "after update_links", params=params, nidx=len(idx))
     G.close()
     runs += 1
+    if time.time() - t_last > 60:
+        t_last = time.time()
+        print(f"... {runs} cases so far", flush=True)
 print(f"soak ok: {runs} random cases (batch, full list, eval, model, incremental rebuild; exact bitwise, fast within 1e-6)")

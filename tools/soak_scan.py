@@ -14,6 +14,7 @@ t_end = time.time() + budget
 base = int(os.environ.get("SOAK_SEED", "20261004"))
 first = int(os.environ.get("SOAK_FIRST", "0"))
 runs = 0
+t_last = time.time()
 while time.time() < t_end:
     rng = np.random.default_rng(base + first + runs)          # one generator per case: a failure is reproducible by its number
     U = int(rng.integers(50, 20000)); I = int(rng.integers(50, 40000)); E = int(rng.integers(U, 12 * (U + I)))
@@ -56,4 +57,7 @@ while time.time() < t_end:
                   [(float(m.rank[i]).hex(), float(r[i]).hex()) for i in bad[:3]], flush=True)
             sys.exit(1)
     runs += 1
+    if time.time() - t_last > 60:
+        t_last = time.time()
+        print(f"... {runs} cases so far", flush=True)
 print(f"soak ok: {runs} random graphs, fold == scan == C restatement bit for bit")
