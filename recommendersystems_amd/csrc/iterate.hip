@@ -626,8 +626,9 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
     if constexpr (G == 1) {
         // single seed, FAST mode: vector-CSR SpMV (re-associated sums are allowed there); EXACT keeps lane = row
         // (the first iterations, while most rows are still exactly 0, run on the list-order kernels below, which
-        //  know how to skip rows without a non-zero in-neighbour: a list-order sum is a valid FAST result)
-        if (g->opts.mode == RWR_MODE_FAST && tg == 1 && !skip && variant != 0 && !act && !nz_out) {
+        //  know how to skip rows without a non-zero in-neighbour: a list-order sum is a valid FAST result;
+        //  and so do graphs beyond the L2s, where the list-order kernels' two-phase row order beats the tree form)
+        if (g->opts.mode == RWR_MODE_FAST && tg == 1 && !skip && variant != 0 && !act && !nz_out && g->n < 2000000) {
             launch_spmv_vector(g, X, Y, c1, s);
             return;
         }
