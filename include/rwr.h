@@ -14,6 +14,8 @@
  *     thread-local UTF-8 message for the last failing call on the calling thread
  *     (the shim turns statuses into the .NET exceptions the reference would throw);
  *   - all pointers are HOST pointers unless a parameter says otherwise;
+ *   - every entry point makes the graph's device current for the call and restores the calling
+ *     thread's current HIP device before it returns;
  *   - handles are independent: distinct rwr_graph handles may be used concurrently from
  *     distinct host threads (the reference runs up to 10 worker threads, each with its
  *     own Graph/Recommender: Program.cs:11,61-66; Experiment.cs:71,104,108).  One handle
@@ -108,6 +110,18 @@ typedef struct rwr_stats {
     int64_t seeds_done;
     int64_t chain_redo_blocks; /* binade scan: blocks the carry had to redo row by row (binade
                                   crossings + mispredicted binades), summed over steps and seeds */
+    /* the DENSE launches among spmm_launches: every row of the matrix is walked and every entry's
+     * source row gathered (no frontier bitmap, no skipped rows).  Only these are priced with the full
+     * algorithmic byte count by bench.py's roofline; the first iterations of a run, which skip the rows
+     * that are still exactly zero, are not */
+    double  spmm_dense_ms;
+    int64_t spmm_dense_launches;
+    int64_t spmm_dense_seed_steps;
+    int32_t uniform_path;    /* 1 when the value-free matrix path serves this graph: every row's weights are
+                                equal (unit raw weights, DataLoader.cs:293-294), so fl(fl((1-d) rank[i]) * weight)
+                                (Model.cs:84,87) is ONE double per source node and step; the kernels gather it and
+                                read no per-entry value (4 instead of 12 matrix bytes per entry) -- bitwise equal */
+    int32_t reserved1;
 } rwr_stats;
 
 /* ---- library ------------------------------------------------------------------------- */
@@ -148,7 +162,10 @@ int32_t rwr_graph_destroy(rwr_graph *g);
  * resident raw lists and re-runs Graph.buildGraph (Graph.cs:51-88) and the transpose on the
  * device; the resulting state is bit for bit what rwr_graph_create would build from the
  * patched lists.  count == 0 just rebuilds.  Not to be called concurrently with other calls
- * on the same handle. */
+ * on the same handle.  Argument errors (RWR_E_INVALID / RWR_E_RANGE) are detected before
+ * anything is patched and leave the graph as it was; a failure AFTER the patch (out of device
+ * memory during the rebuild, a HIP error) invalidates the handle: every later call on it
+ * fails with RWR_E_INVALID until it is destroyed. */
 int32_t rwr_graph_update_links(rwr_graph *g, int64_t count, const int64_t *link_index,
                                const uint8_t *etype /* may be NULL */, const double *w /* may be NULL */);
 /* Graph.size() (Graph.cs:91-93) plus link counts; any out pointer may be NULL */
@@ -167,8 +184,9 @@ int32_t rwr_graph_get_normalized(rwr_graph *g, double *w_out /* nnz_raw */, uint
  * d crosses as float and is widened natively, as Recommender.cs:16 -> Model.cs:33 does.
  * top_n <= 0 returns the whole list (the reference's Count == topN test never fires).
  * Domain: raw weights >= 0 with a positive finite sum per node (what the reference's loader
- * produces); on a graph with a negative / NaN weight or a zero row sum the Recommendation
- * entries fail with RWR_E_UNSUPPORTED (rwr_model_run still reproduces the reference there).
+ * produces) and 0 <= d <= 1; on a graph with a negative / NaN weight or a zero row sum, or
+ * for a damping factor outside [0, 1] (ranks would go negative), the Recommendation entries
+ * fail with RWR_E_UNSUPPORTED (rwr_model_run still reproduces the reference there).
  * in:  *inout_count = capacity of out_id/out_score;  out: entries written.  If the list
  * needs more room the call fails with RWR_E_CAPACITY and *inout_count = required size
  * (n always suffices). */

@@ -37,7 +37,9 @@ class rwr_stats(C.Structure):
                 ("build_ms", C.c_double), ("spmm_ms", C.c_double), ("spmm_launches", C.c_int64),
                 ("spmm_seed_steps", C.c_int64), ("chain_ms", C.c_double), ("chain_launches", C.c_int64),
                 ("rank_ms", C.c_double), ("iterate_wall_ms", C.c_double), ("total_wall_ms", C.c_double),
-                ("seeds_done", C.c_int64), ("chain_redo_blocks", C.c_int64)]
+                ("seeds_done", C.c_int64), ("chain_redo_blocks", C.c_int64),
+                ("spmm_dense_ms", C.c_double), ("spmm_dense_launches", C.c_int64), ("spmm_dense_seed_steps", C.c_int64),
+                ("uniform_path", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class RwrError(RuntimeError):

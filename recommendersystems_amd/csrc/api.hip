@@ -29,11 +29,39 @@ static int usable_devices()
     return n;
 }
 
-static int32_t bind_device(const rwr_graph *g)
-{
-    RWR_HIP(hipSetDevice(g->device));
-    return RWR_OK;
-}
+// Makes the graph's device current for the duration of one entry point and gives the caller's device back on every
+// return path: a host that shares the thread with PyTorch / RCCL keeps its own current device.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    int32_t rc = RWR_OK;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != device) {
+            hipError_t e = hipSetDevice(device);
+            if (e != hipSuccess) {
+                set_error("hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+                rc = RWR_E_HIP;
+                return;
+            }
+            switched = true;
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define RWR_BIND(g)                                                                                              \
+    if ((g)->poisoned) {                                                                                         \
+        rwr::set_error("this graph handle was invalidated by a failed rwr_graph_update_links; destroy it");       \
+        return RWR_E_INVALID;                                                                                    \
+    }                                                                                                            \
+    rwr::DeviceGuard dev_guard__((g)->device);                                                                   \
+    if (dev_guard__.rc != RWR_OK) return dev_guard__.rc
 
 }  // namespace rwr
 
@@ -115,7 +143,8 @@ int32_t rwr_graph_create(int32_t n, const int64_t *node_id, const uint8_t *node_
         rwr_graph_destroy(g);
         return code;
     };
-    if (hipSetDevice(g->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", g->device); return fail(RWR_E_HIP); }
+    rwr::DeviceGuard dev_guard(g->device);
+    if (dev_guard.rc != RWR_OK) return fail(dev_guard.rc);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, g->device) != hipSuccess) { set_error("hipGetDeviceProperties failed"); return fail(RWR_E_HIP); }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -155,14 +184,17 @@ int32_t rwr_graph_update_links(rwr_graph *g, int64_t count, const int64_t *link_
         set_error("rwr_graph_update_links: count must be >= 0 and link_index non-NULL when count > 0");
         return RWR_E_INVALID;
     }
-    if (hipSetDevice(g->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", g->device); return RWR_E_HIP; }
-    return graph_update_links(g, count, link_index, etype, w);
+    RWR_BIND(g);
+    const int32_t rc = graph_update_links(g, count, link_index, etype, w);
+    // a failure after the raw lists were patched leaves derived arrays that no longer match them
+    if (rc != RWR_OK && rc != RWR_E_RANGE && rc != RWR_E_INVALID) g->poisoned = 1;
+    return rc;
 }
 
 int32_t rwr_graph_destroy(rwr_graph *g)
 {
     if (!g) return RWR_OK;
-    (void)hipSetDevice(g->device);
+    rwr::DeviceGuard dev_guard(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->stream2) (void)hipStreamSynchronize(g->stream2);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
@@ -188,7 +220,7 @@ int32_t rwr_graph_get_normalized(rwr_graph *g, double *w_out, uint8_t *dangling_
 {
     g_err[0] = 0;
     if (!g) { set_error("rwr_graph_get_normalized: graph is NULL"); return RWR_E_INVALID; }
-    RWR_TRY(bind_device(g));
+    RWR_BIND(g);
     if (w_out && g->nnz_raw > 0)
         RWR_HIP(hipMemcpy(w_out, g->w_norm_raw.p, sizeof(double) * (size_t)g->nnz_raw, hipMemcpyDeviceToHost));
     if (dangling_out) RWR_HIP(hipMemcpy(dangling_out, g->dangling.p, (size_t)g->n, hipMemcpyDeviceToHost));
@@ -203,7 +235,7 @@ int32_t rwr_recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, float
     if (K <= 0) { set_error("rwr_recommend_batch: K must be >= 1"); return RWR_E_INVALID; }
     if (top_n < 1) { set_error("rwr_recommend_batch: top_n must be >= 1"); return RWR_E_INVALID; }
     if (n_iter < 0) n_iter = 0;   // Model.run(int): a non-positive count runs no iteration (Model.cs:69)
-    RWR_TRY(bind_device(g));
+    RWR_BIND(g);
     // Recommender.cs:14,16 -> Model.cs:33: the float is widened to double
     return recommend_batch(g, seeds, K, (double)d, n_iter, top_n, ids, scores, counts, top_n);
 }
@@ -215,7 +247,7 @@ int32_t rwr_recommend(rwr_graph *g, int32_t seed, float d, int32_t n_iter, int32
     if (!g || !inout_count) { set_error("rwr_recommend: NULL argument"); return RWR_E_INVALID; }
     if (seed < 0 || seed >= g->n) { set_error("seed %d is outside [0, %d)", seed, g->n); return RWR_E_RANGE; }
     if (n_iter < 0) n_iter = 0;
-    RWR_TRY(bind_device(g));
+    RWR_BIND(g);
     // Recommender.cs:42-51: topN <= 0 never truncates
     int64_t width = (top_n > 0 && top_n < g->n_items) ? top_n : g->n_items;
     if (width == 0) { *inout_count = 0; return RWR_OK; }
@@ -249,7 +281,7 @@ int32_t rwr_recommend_eval(rwr_graph *g, int32_t seed, float d, int32_t n_iter, 
     if (seed < 0 || seed >= g->n) { set_error("seed %d is outside [0, %d)", seed, g->n); return RWR_E_RANGE; }
     if (n_test > 0x7FFFFFFF) { set_error("rwr_recommend_eval: test set too large"); return RWR_E_UNSUPPORTED; }
     if (n_iter < 0) n_iter = 0;
-    RWR_TRY(bind_device(g));
+    RWR_BIND(g);
     *n_hits = 0;
     *sum_precision = 0.0;
     if (list_len) *list_len = 0;
@@ -269,7 +301,7 @@ int32_t rwr_model_deliver(rwr_graph *g, int32_t seed, double d, const double *ra
 {
     g_err[0] = 0;
     if (!g || !rank || !next_rank || rank == next_rank) { set_error("rwr_model_deliver: NULL or aliasing argument"); return RWR_E_INVALID; }
-    RWR_TRY(bind_device(g));
+    RWR_BIND(g);
     return model_deliver(g, seed, d, rank, next_rank);
 }
 
@@ -278,7 +310,7 @@ int32_t rwr_model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, do
 {
     g_err[0] = 0;
     if (!g || !rank_out) { set_error("rwr_model_run: NULL argument"); return RWR_E_INVALID; }
-    RWR_TRY(bind_device(g));
+    RWR_BIND(g);
     if (run_mode != RWR_RUN_ITERATIONS && run_mode != RWR_RUN_THRESHOLD && run_mode != RWR_RUN_DEFAULT_THRESHOLD) {
         set_error("rwr_model_run: unknown run_mode %d", run_mode);
         return RWR_E_INVALID;
@@ -292,7 +324,7 @@ int32_t rwr_part_begin(rwr_graph *g, int32_t slab_lo, int32_t slab_hi, const int
 {
     g_err[0] = 0;
     if (!g || !seeds || !dev_x) { set_error("rwr_part_begin: NULL argument"); return RWR_E_INVALID; }
-    RWR_TRY(bind_device(g));
+    RWR_BIND(g);
     return part_begin(g, slab_lo, slab_hi, seeds, K, d, (double *)dev_x, tile_seeds_out);
 }
 
@@ -300,7 +332,7 @@ int32_t rwr_part_local_step(rwr_graph *g, const void *dev_x, void *dev_y, void *
 {
     g_err[0] = 0;
     if (!g || !dev_x || !dev_y || !dev_r) { set_error("rwr_part_local_step: NULL argument"); return RWR_E_INVALID; }
-    RWR_TRY(bind_device(g));
+    RWR_BIND(g);
     return part_local_step(g, (const double *)dev_x, (double *)dev_y, (double *)dev_r);
 }
 
@@ -308,7 +340,7 @@ int32_t rwr_part_finish_step(rwr_graph *g, void *dev_y, const void *dev_r)
 {
     g_err[0] = 0;
     if (!g || !dev_y || !dev_r) { set_error("rwr_part_finish_step: NULL argument"); return RWR_E_INVALID; }
-    RWR_TRY(bind_device(g));
+    RWR_BIND(g);
     return part_finish_step(g, (double *)dev_y, (const double *)dev_r);
 }
 
@@ -316,7 +348,7 @@ int32_t rwr_part_rank(rwr_graph *g, void *dev_x, int32_t top_n, int64_t *ids, do
 {
     g_err[0] = 0;
     if (!g || !dev_x || !ids || !scores || !counts) { set_error("rwr_part_rank: NULL argument"); return RWR_E_INVALID; }
-    RWR_TRY(bind_device(g));
+    RWR_BIND(g);
     return part_rank(g, (double *)dev_x, top_n, ids, scores, counts);
 }
 
@@ -337,6 +369,8 @@ int32_t rwr_reset_stats(rwr_graph *g)
     rwr_stats &s = g->stats;
     s.spmm_ms = s.chain_ms = s.rank_ms = s.iterate_wall_ms = s.total_wall_ms = 0;
     s.spmm_launches = s.spmm_seed_steps = s.chain_launches = s.seeds_done = s.chain_redo_blocks = 0;
+    s.spmm_dense_ms = 0;
+    s.spmm_dense_launches = s.spmm_dense_seed_steps = 0;
     return RWR_OK;
 }
 

@@ -76,7 +76,15 @@ __global__ __launch_bounds__(256) void k_gather_in(const uint32_t *__restrict__ 
     if (p >= nnz) return;
     uint32_t e = sval[p];
     in_src[p] = esrc[e];
-    in_w[p] = w_norm[e];
+    if (in_w) in_w[p] = w_norm[e];     // (value-free graphs keep no per-entry weights)
+}
+
+// value-free graphs: the weight of entry p is the one weight of its source
+__global__ __launch_bounds__(256) void k_fill_in_w(int64_t nnz, const int32_t *__restrict__ in_src,
+                                                   const double *__restrict__ w_src, double *__restrict__ in_w)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nnz) in_w[p] = w_src[in_src[p]];
 }
 
 __global__ __launch_bounds__(256) void k_order_keys(int32_t n, const int64_t *__restrict__ in_ptr,
@@ -289,11 +297,14 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     g->nnz = nnz;
     g->uniform = h_flags[0] ? 0 : 1;
     g->nonneg = h_flags[3] ? 0 : 1;
+    static const int vf_env = [] { const char *e = getenv("RWR_VALUE_FREE"); return e ? atoi(e) : 1; }();
+    g->vf = (g->uniform && g->nonneg && vf_env) ? 1 : 0;
     RWR_TRY(g->in_src.ensure((size_t)nnz));
-    RWR_TRY(g->in_w.ensure((size_t)nnz));
+    if (g->vf) g->in_w.release();
+    else RWR_TRY(g->in_w.ensure((size_t)nnz));
     if (nnz > 0) {
         hipLaunchKernelGGL(k_gather_in, dim3(cdiv((size_t)nnz, 256)), dim3(256), 0, s, v_sorted, nnz, esrc.p,
-                           g->w_norm_raw.p, g->in_src.p, g->in_w.p);
+                           g->w_norm_raw.p, g->in_src.p, g->vf ? (double *)nullptr : g->in_w.p);
         RWR_HIP(hipGetLastError());
     }
 
@@ -359,6 +370,20 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     g->stats.build_ms = ms;
     g->stats.nnz = g->nnz;
     g->stats.uniform = g->uniform;
+    g->stats.uniform_path = g->vf;
+    return RWR_OK;
+}
+
+int32_t ensure_in_w(rwr_graph *g)
+{
+    if (g->in_w.p && g->in_w.count >= (size_t)(g->nnz > 0 ? g->nnz : 1)) return RWR_OK;
+    RWR_TRY(g->in_w.alloc((size_t)g->nnz));
+    if (g->nnz > 0) {
+        // (uniform rows: w_src[i] = first / sum is bit for bit w[p] / sum of every explicit link p of i, Graph.cs:81)
+        hipLaunchKernelGGL(k_fill_in_w, dim3(cdiv((size_t)g->nnz, 256)), dim3(256), 0, g->stream, g->nnz, g->in_src.p,
+                           g->w_src.p, g->in_w.p);
+        RWR_HIP(hipGetLastError());
+    }
     return RWR_OK;
 }
 

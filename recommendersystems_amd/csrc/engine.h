@@ -1,5 +1,7 @@
 // Device-resident graph and batch workspace (internal).
 #pragma once
+#include <cstdlib>
+
 #include "common.h"
 
 struct rwr_graph {
@@ -9,9 +11,18 @@ struct rwr_graph {
     int64_t nnz = 0;         // explicit links = entries of the transition matrix
     int32_t n_items = 0;     // nodes of type ITEM
     int32_t uniform = 0;     // every row's explicit raw weights equal
+    // Value-free matrix path (uniform && nonneg, RWR_VALUE_FREE != 0).  Every out-link of source i then carries the SAME
+    // normalised weight w_src[i] (Graph.cs:79-81 divides equal raw weights by one sum), so the product Model.cs:87 adds,
+    //     fl( fl((1-d) * rank[i]) * weight ),
+    // is one and the same double for all links of i: it is formed once per node and step (z[i], written by the kernel
+    // that produced rank[i]) and the SpMM / SpMV gather z and read NO per-entry value -- 4 instead of 12 matrix bytes per
+    // entry and one add per entry, bit for bit the reference's sums.  in_w is not even built on such graphs
+    // (ensure_in_w materialises it for the few entry points that still take the weighted kernels).
+    int32_t vf = 0;
     int32_t nonneg = 1;      // every normalised weight is a finite number >= 0 (raw weights >= 0, row sums in (0, inf)): ranks stay
                              // >= 0, which the zero-skipping frontier paths and the binade scan rely on; otherwise the general kernels run
     int32_t max_in_deg = 0;
+    int32_t poisoned = 0;    // a failed incremental rebuild left raw and derived arrays out of step: every entry point refuses
     // rows of row_order (in-degree descending) with in-degree >= 128 / >= 32 / >= 4: lane-width bins of the K = 1 vector SpMV
     int32_t bin_end[3] = {0, 0, 0};
     int32_t bin_huge = 0;    // rows with in-degree >= 2048: one 1024-thread workgroup per row
@@ -50,6 +61,7 @@ struct rwr_graph {
 
     // batch workspace (lazily sized)
     rwr::DevBuf<double> X, Y;         // rank matrices [tile][n][G]
+    rwr::DevBuf<double> Z0, Z1;       // value-free path: z = ((1-d) x) * w_src of the current / next ranks, same layout
     rwr::DevBuf<int32_t> d_seeds;     // [tile][G], -1 = padding lane
     rwr::DevBuf<int32_t> d_slot_k;    // [tile][G]: batch position of the seed in this slot (-1 = padding)
     rwr::DevBuf<double> d_part;       // fast mode: restart partial sums
@@ -83,14 +95,26 @@ struct rwr_graph {
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;   // profiling pairs
 
     rwr_stats stats{};
+    std::vector<uint8_t> spmm_ev_dense;   // per profiled SpMM launch: 1 = dense (no frontier skipping)
 };
 
 namespace rwr {
+
+// Node count from which a graph counts as "beyond the L2s" (its rank vector no longer fits them): two-phase row order of
+// the single-seed SpMV, one more frontier iteration, FAST single seed on the list-order kernels, 32-seed tiles.
+// RWR_BIG_N overrides the default of 2 M so that small test graphs can reach the same code paths.
+inline int32_t spmv_big_n()
+{
+    static const int32_t v = [] { const char *e = getenv("RWR_BIG_N"); return e ? (int32_t)atol(e) : (int32_t)2000000; }();
+    return v;
+}
 
 int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_type, const int64_t *rowptr,
                     const int32_t *dst, const uint8_t *etype, const double *w);
 
 int32_t graph_update_links(rwr_graph *g, int64_t count, const int64_t *idx, const uint8_t *etype, const double *w);
+// value-free graphs: materialise in_w (= w_src[in_src]) for an entry point that runs the weighted kernels
+int32_t ensure_in_w(rwr_graph *g);
 
 // runs the power iteration for K seeds and leaves, per seed, the ranked list
 // (mode 0: top-k into host arrays; mode 1: full rank vector of one seed)
@@ -107,9 +131,12 @@ int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double
                   int64_t *iters_out);
 int32_t model_deliver(rwr_graph *g, int32_t seed, double d, const double *rank_in, double *next_out);
 // spmv.hip: single-seed SpMV (EXACT: list-order sums, rows binned by in-degree; FAST: vector-CSR with tree reductions)
+// (zin != nullptr: value-free form -- gathers zin, reads no per-entry value; zout (may be nullptr) receives the next z)
 void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *seeds, double c1, int skip,
-                       const uint32_t *act, uint32_t *nz_out, hipStream_t s);
-void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hipStream_t s);
+                       const uint32_t *act, uint32_t *nz_out, hipStream_t s, const double *zin = nullptr,
+                       double *zout = nullptr);
+void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hipStream_t s, const double *zin = nullptr,
+                        double *zout = nullptr);
 // chain_scan.hip: the exact seed-row chain as a parallel binade scan
 int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, hipStream_t s);
 int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,

@@ -29,13 +29,17 @@
 
 namespace rwr {
 
-template <int G>
+// VF = value-free form (engine.h: rwr_graph::vf): X is then the z matrix -- z[i] = ((1-d) x[i]) * w_src[i], the one
+// product Model.cs:87 adds for EVERY link of source i -- no per-entry value is read, a row's sum is the plain list-order
+// sum of the gathered z, and the epilogue forms the row's own z for the next step (Zout, may be null on the last one).
+template <int G, bool VF>
 __global__ __launch_bounds__(256) void k_spmm(int32_t n, const int64_t *__restrict__ in_ptr,
                                               const int32_t *__restrict__ in_src,
                                               const double *__restrict__ in_w,
                                               const int32_t *__restrict__ row_order,
                                               const double *__restrict__ X, double *__restrict__ Y,
-                                              const int32_t *__restrict__ seeds, double c1, int skip_seed_row)
+                                              const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
+                                              const double *__restrict__ w_src, double *__restrict__ Zout)
 {
     constexpr int RPW = WAVE / G;   // destination rows per wave
     constexpr int U = 4;            // gathers in flight per lane
@@ -43,6 +47,7 @@ __global__ __launch_bounds__(256) void k_spmm(int32_t n, const int64_t *__restri
     const size_t toff = (size_t)tile * (size_t)n * G;
     X += toff;
     Y += toff;
+    if (VF && Zout) Zout += toff;
     const int lane = threadIdx.x & (WAVE - 1);
     const int sub = lane / G, k = lane % G;
     const int32_t my_seed = skip_seed_row ? seeds[tile * G + k] : -1;
@@ -64,20 +69,31 @@ __global__ __launch_bounds__(256) void k_spmm(int32_t n, const int64_t *__restri
 #pragma unroll
             for (int u = 0; u < U; ++u) idx[u] = in_src[p + u];
 #pragma unroll
-            for (int u = 0; u < U; ++u) wv[u] = in_w[p + u];
+            for (int u = 0; u < U; ++u) wv[u] = VF ? 0.0 : in_w[p + u];
 #pragma unroll
             for (int u = 0; u < U; ++u) xv[u] = X[(size_t)idx[u] * G + k];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                double rw = c1 * xv[u];          // Model.cs:84
-                acc += rw * wv[u];               // Model.cs:87
+                if (VF) {
+                    acc += xv[u];                // z of the source: the product of Model.cs:84,87, formed once per node
+                } else {
+                    double rw = c1 * xv[u];      // Model.cs:84
+                    acc += rw * wv[u];           // Model.cs:87
+                }
             }
         }
         for (; p < e; ++p) {
-            double rw = c1 * X[(size_t)in_src[p] * G + k];
-            acc += rw * in_w[p];
+            if (VF) {
+                acc += X[(size_t)in_src[p] * G + k];
+            } else {
+                double rw = c1 * X[(size_t)in_src[p] * G + k];
+                acc += rw * in_w[p];
+            }
         }
-        if (j >= 0 && j != my_seed) Y[(size_t)j * G + k] = acc;
+        if (j >= 0 && j != my_seed) {
+            Y[(size_t)j * G + k] = acc;
+            if (VF && Zout) { const double rw = c1 * acc; Zout[(size_t)j * G + k] = rw * w_src[j]; }
+        }
     }
 }
 
@@ -91,7 +107,9 @@ __global__ __launch_bounds__(256) void k_spmm(int32_t n, const int64_t *__restri
 // sparse for two or three steps): CHECK consults a per-tile bitmap "row of X has a non-zero" before a
 // row gather and skips the gather of all-zero rows -- their addends are (1-d)*0*w = +0.0, which leave
 // the non-negative accumulator bitwise unchanged.  WRITE records the non-zero rows of Y for the next step.
-template <int G, int CH, bool CHECK, bool WRITE>
+// VF: the value-free form (see k_spmm): X is the z matrix, one index load + one bpermute + one gather + ONE add per
+// entry, no weight stream, no multiplies; the epilogue writes the row's next z.
+template <int G, int CH, bool CHECK, bool WRITE, bool VF>
 __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *__restrict__ in_ptr,
                                                       const int32_t *__restrict__ in_src,
                                                       const double *__restrict__ in_w,
@@ -100,7 +118,8 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
                                                       const int32_t *__restrict__ seeds, double c1,
                                                       int skip_seed_row, const uint32_t *__restrict__ nz_in,
                                                       uint32_t *__restrict__ nz_out,
-                                                      const uint32_t *__restrict__ act)
+                                                      const uint32_t *__restrict__ act,
+                                                      const double *__restrict__ w_src, double *__restrict__ Zout)
 {
     static_assert(G >= 8 && G <= 64, "chunked SpMM needs 8 <= G <= 64");
     constexpr int RPW = WAVE / G;
@@ -108,6 +127,7 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
     const size_t toff = (size_t)tile * (size_t)n * G;
     X += toff;
     Y += toff;
+    if (VF && Zout) Zout += toff;
     const size_t nzw = ((size_t)n + 31) / 32;
     if (CHECK) nz_in += (size_t)tile * nzw;
     if (WRITE) nz_out += (size_t)tile * nzw;
@@ -138,7 +158,7 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
             double my_w = 0.0;
             if (k < cnt) {
                 my_idx = in_src[p + k];
-                my_w = in_w[p + k];
+                if (!VF) my_w = in_w[p + k];
                 if (CHECK) {   // one bitmap probe per entry (by the lane that fetched it); dead rows get the sign bit
                     const uint32_t wd = nz_in[(uint32_t)my_idx >> 5];
                     if (!((wd >> (my_idx & 31)) & 1u)) my_idx |= (int32_t)0x80000000;
@@ -160,11 +180,15 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
                         const int t = __builtin_ctzll(um);
                         um &= um - 1;
                         const int idx = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), my_idx);
-                        const int lo = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), wlo);
-                        const int hi = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), whi);
-                        if (t < cnt && idx >= 0) {
-                            const double rw = c1 * X[(size_t)idx * G + k];   // Model.cs:84
-                            acc += rw * __hiloint2double(hi, lo);             // Model.cs:87
+                        if (VF) {
+                            if (t < cnt && idx >= 0) acc += X[(size_t)idx * G + k];
+                        } else {
+                            const int lo = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), wlo);
+                            const int hi = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), whi);
+                            if (t < cnt && idx >= 0) {
+                                const double rw = c1 * X[(size_t)idx * G + k];   // Model.cs:84
+                                acc += rw * __hiloint2double(hi, lo);             // Model.cs:87
+                            }
                         }
                     }
                     p += cnt;
@@ -175,21 +199,30 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
 #pragma unroll
             for (int t = 0; t < CH; ++t) {
                 const int idx = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), my_idx);
-                const int lo = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), wlo);
-                const int hi = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), whi);
-                wv[t] = __hiloint2double(hi, lo);
+                if (!VF) {
+                    const int lo = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), wlo);
+                    const int hi = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), whi);
+                    wv[t] = __hiloint2double(hi, lo);
+                }
                 xv[t] = (t < cnt && idx >= 0) ? X[(size_t)idx * G + k] : 0.0;
             }
 #pragma unroll
             for (int t = 0; t < CH; ++t) {
                 if (t < cnt) {
-                    double rw = c1 * xv[t];      // Model.cs:84
-                    acc += rw * wv[t];           // Model.cs:87
+                    if (VF) {
+                        acc += xv[t];                // the source's z: fl(fl((1-d) x) * w), Model.cs:84,87
+                    } else {
+                        double rw = c1 * xv[t];      // Model.cs:84
+                        acc += rw * wv[t];           // Model.cs:87
+                    }
                 }
             }
             p += cnt;
         }
-        if (j >= 0 && j != my_seed) Y[(size_t)j * G + k] = acc;
+        if (j >= 0 && j != my_seed) {
+            Y[(size_t)j * G + k] = acc;
+            if (VF && Zout) { const double rw = c1 * acc; Zout[(size_t)j * G + k] = rw * w_src[j]; }
+        }
         if (WRITE) {
             const unsigned long long nzb = __ballot(acc != 0.0);
             const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << (sub * G));
@@ -297,7 +330,8 @@ __global__ void k_gate(const unsigned int *__restrict__ gate, unsigned int expec
 
 // EXACT mode helper: the addends of the links INTO each seed, ((1-d) x_src) * w in list order
 // (Model.cs:84,87 for target == seed), computed in parallel ahead of the sequential fold.
-template <int G>
+// (VF: X is the z matrix, whose entries ARE those addends)
+template <int G, bool VF>
 __global__ __launch_bounds__(256) void k_seed_terms(int32_t n, const int64_t *__restrict__ in_ptr,
                                                     const int32_t *__restrict__ in_src,
                                                     const double *__restrict__ in_w, const double *__restrict__ X,
@@ -312,8 +346,12 @@ __global__ __launch_bounds__(256) void k_seed_terms(int32_t n, const int64_t *__
     const int64_t p0 = in_ptr[s], deg = in_ptr[s + 1] - p0;
     double *out = evterm + evoff[slot];
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < deg; q += (int64_t)gridDim.x * blockDim.x) {
-        const double rw = c1 * x[(size_t)in_src[p0 + q] * G];
-        out[q] = rw * in_w[p0 + q];
+        if (VF) {
+            out[q] = x[(size_t)in_src[p0 + q] * G];
+        } else {
+            const double rw = c1 * x[(size_t)in_src[p0 + q] * G];
+            out[q] = rw * in_w[p0 + q];
+        }
     }
 }
 
@@ -584,14 +622,17 @@ __global__ __launch_bounds__(64) void k_restart_final(int32_t n, int ntiles, int
 }
 
 // Model ctor, Model.cs:42-49: rank[seed] = nNodes, everything else 0
+// (value-free path: Z receives the seed's z, ((1-d) n) * w_src[seed])
 __global__ void k_init_seeds(int32_t n, int ntiles, int G, double *__restrict__ X,
-                             const int32_t *__restrict__ seeds, uint32_t *__restrict__ nz)
+                             const int32_t *__restrict__ seeds, uint32_t *__restrict__ nz,
+                             double *__restrict__ Z = nullptr, const double *__restrict__ w_src = nullptr, double c1 = 0.0)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= ntiles * G) return;
     const int32_t s = seeds[q];
     if (s < 0) return;
     X[(size_t)(q / G) * (size_t)n * G + (size_t)s * G + (q % G)] = (double)n;
+    if (Z) { const double rw = c1 * (double)n; Z[(size_t)(q / G) * (size_t)n * G + (size_t)s * G + (q % G)] = rw * w_src[s]; }
     if (nz) atomicOr(&nz[(size_t)(q / G) * (((size_t)n + 31) / 32) + ((uint32_t)s >> 5)], 1u << (s & 31));
 }
 
@@ -612,13 +653,39 @@ __global__ __launch_bounds__(64) void k_exclude(int32_t n, int ntiles, int G, co
         if (etype[p] == RWR_EDGE_LIKE) x[(size_t)dst[p] * G] = -1.0;
 }
 
+// value-free path: the z of the seeds' own rows, once the seed-row kernel (chain / scan / restart reduction) has
+// left their final rank in Y:  z = ((1-d) * y) * w_src   (the product of Model.cs:84,87 for the next step)
+__global__ void k_seed_z(int32_t n, int ntiles, int G, const double *__restrict__ Y, double *__restrict__ Z,
+                         const int32_t *__restrict__ seeds, const double *__restrict__ w_src, double c1)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ntiles * G) return;
+    const int32_t s = seeds[q];
+    if (s < 0) return;
+    const size_t at = (size_t)(q / G) * (size_t)n * G + (size_t)s * G + (q % G);
+    const double rw = c1 * Y[at];
+    Z[at] = rw * w_src[s];
+}
+// value-free path, rank vector supplied by the caller (Model.deliverRanks on its own): z of every row
+__global__ __launch_bounds__(256) void k_make_z(int64_t elems, int G, const double *__restrict__ X, double *__restrict__ Z,
+                                                const double *__restrict__ w_src, double c1)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= elems) return;
+    const double rw = c1 * X[q];
+    Z[q] = rw * w_src[q / G];
+}
+
 // ------------------------------------------------------------------------------ host side
 
 template <int G>
 static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
                         int skip, const uint32_t *nz_in, uint32_t *nz_out, hipStream_t s,
-                        const uint32_t *act = nullptr)
+                        const uint32_t *act = nullptr, const double *Zin = nullptr, double *Zout = nullptr)
 {
+    // Zin != nullptr: value-free form -- the kernels gather Zin (z of the current ranks) instead of X and read no weights
+    const bool vf = Zin != nullptr;
+    const double *GS = vf ? Zin : X;   // gather source
     constexpr int RPW = WAVE / G;
     unsigned want = cdiv((size_t)g->n, (size_t)RPW * 4);
     unsigned gx = want < 8192u ? want : 8192u;
@@ -628,48 +695,63 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
         // (the first iterations, while most rows are still exactly 0, run on the list-order kernels below, which
         //  know how to skip rows without a non-zero in-neighbour: a list-order sum is a valid FAST result;
         //  and so do graphs beyond the L2s, where the list-order kernels' two-phase row order beats the tree form)
-        if (g->opts.mode == RWR_MODE_FAST && tg == 1 && !skip && variant != 0 && !act && !nz_out && g->n < 2000000) {
-            launch_spmv_vector(g, X, Y, c1, s);
+        if (g->opts.mode == RWR_MODE_FAST && tg == 1 && !skip && variant != 0 && !act && !nz_out && g->n < spmv_big_n()) {
+            launch_spmv_vector(g, X, Y, c1, s, Zin, Zout);
             return;
         }
         if (tg == 1 && variant != 0) {
-            launch_spmv_exact(g, X, Y, seeds, c1, skip, act, nz_out, s);
+            launch_spmv_exact(g, X, Y, seeds, c1, skip, act, nz_out, s, Zin, Zout);
             return;
         }
     }
     if constexpr (G >= 8) {
         if (variant != 0) {
-#define RWR_SPMM_LAUNCH2(CH, CHK, WR)                                                                              \
-    hipLaunchKernelGGL((k_spmm_chunked<G, CH, CHK, WR>), dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p,         \
-                       g->in_src.p, g->in_w.p, g->row_order.p, X, Y, seeds, c1, skip, nz_in, nz_out, act)
+#define RWR_SPMM_LAUNCH3(CH, CHK, WR, VFF)                                                                         \
+    hipLaunchKernelGGL((k_spmm_chunked<G, CH, CHK, WR, VFF>), dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p,    \
+                       g->in_src.p, g->in_w.p, g->row_order.p, GS, Y, seeds, c1, skip, nz_in, nz_out, act,         \
+                       g->w_src.p, Zout)
+#define RWR_SPMM_LAUNCH2(CH, CHK, WR)                    \
+    {                                                    \
+        if (vf) RWR_SPMM_LAUNCH3(CH, CHK, WR, true);     \
+        else RWR_SPMM_LAUNCH3(CH, CHK, WR, false);       \
+    }
 #define RWR_SPMM_LAUNCH(CH)                                  \
     {                                                        \
-        if (nz_in && nz_out) RWR_SPMM_LAUNCH2(CH, true, true);   \
-        else if (nz_in) RWR_SPMM_LAUNCH2(CH, true, false);       \
-        else RWR_SPMM_LAUNCH2(CH, false, false);                 \
+        if (nz_in && nz_out) RWR_SPMM_LAUNCH2(CH, true, true)    \
+        else if (nz_in) RWR_SPMM_LAUNCH2(CH, true, false)        \
+        else RWR_SPMM_LAUNCH2(CH, false, false)                  \
     }
             // entries per chunk = row gathers in flight per lane (variant 2: 8, variant 3: 4)
             if (variant == 2) RWR_SPMM_LAUNCH(8)
             else if (variant == 3) RWR_SPMM_LAUNCH(4)
             else RWR_SPMM_LAUNCH((G > 16 ? 16 : G))
+#undef RWR_SPMM_LAUNCH3
 #undef RWR_SPMM_LAUNCH2
 #undef RWR_SPMM_LAUNCH
             return;
         }
     }
-    hipLaunchKernelGGL(k_spmm<G>, dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p, g->in_w.p,
-                       g->row_order.p, X, Y, seeds, c1, skip);
+    if (vf)
+        hipLaunchKernelGGL((k_spmm<G, true>), dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p, g->in_w.p,
+                           g->row_order.p, GS, Y, seeds, c1, skip, g->w_src.p, Zout);
+    else
+        hipLaunchKernelGGL((k_spmm<G, false>), dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p, g->in_w.p,
+                           g->row_order.p, GS, Y, seeds, c1, skip, g->w_src.p, Zout);
 }
 template <int G>
 // the addends of the links into the seeds; tiny, runs on the MAIN stream ahead of the fork so that the chain kernel is
 // the first thing its stream has to dispatch once the fork event fires (it must get its CUs before the SpMM's
 // half-million workgroups flood the dispatcher, or it only starts when the SpMM drains)
 static void launch_seed_terms(rwr_graph *g, int tg, const double *X, const int32_t *seeds, double c1,
-                              const int64_t *evoff, hipStream_t s)
+                              const int64_t *evoff, hipStream_t s, const double *Zin)
 {
     const unsigned term_blocks = g->max_in_deg > 256 * 8 ? 8u : cdiv((size_t)(g->max_in_deg > 0 ? g->max_in_deg : 1), 256);
-    hipLaunchKernelGGL(k_seed_terms<G>, dim3(term_blocks, tg * G), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p,
-                       g->in_w.p, X, seeds, c1, evoff, g->d_evterm.p);
+    if (Zin)
+        hipLaunchKernelGGL((k_seed_terms<G, true>), dim3(term_blocks, tg * G), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p,
+                           g->in_w.p, Zin, seeds, c1, evoff, g->d_evterm.p);
+    else
+        hipLaunchKernelGGL((k_seed_terms<G, false>), dim3(term_blocks, tg * G), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p,
+                           g->in_w.p, X, seeds, c1, evoff, g->d_evterm.p);
 }
 template <int G>
 static void launch_chain(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
@@ -754,7 +836,7 @@ static int resolve_G(const rwr_graph *g, int32_t K)
     // half the per-entry instruction work of 16, while 64 gains nothing more and lengthens the seed-row chain
     // (on the 20M-link graph 16 is a little faster: the ranking stage scales with the tile width)
     // ... and 32 again wins on dense graphs (hundreds of links per node: the MovieLens-shaped config, +10 %)
-    const int cap = (g->n >= 2000000 || g->nnz / (g->n > 0 ? g->n : 1) >= 64) ? 32 : 16;
+    const int cap = (g->n >= spmv_big_n() || g->nnz / (g->n > 0 ? g->n : 1) >= 64) ? 32 : 16;
     int want = 1;
     while (want < K && want < cap) want <<= 1;
     return want;
@@ -769,16 +851,18 @@ struct GroupIter {
     const int64_t *d_evoff;
     double c1;
     double *X, *Y;
+    double *Zc = nullptr, *Zn = nullptr;   // value-free path: z of the current ranks / of the ranks being produced
     uint32_t *nz_cur = nullptr, *nz_oth = nullptr;
     int nz_iters = 0;
     int64_t it = 0;
     bool scan = false;   // exact mode: seed-row chain by the parallel binade scan (chain_scan.hip)
     int chain_kind = 1;  // 0 simple one-lane loop, 1 auto, 2 scan, 3 role-specialised fold
     int act_iters = 0;   // iterations whose SpMM only visits the out-neighbours of non-zero rows
+    int64_t dense_steps = 0;   // steps whose SpMM walked every row (no frontier bitmap)
 
     GroupIter(rwr_graph *g_, int G_, int tg_, const int32_t *seeds, const int64_t *evoff, double d)
         : g(g_), G(G_), tg(tg_), d_seeds(seeds), d_evoff(evoff), c1(1 - d) /* Model.cs:84: (1 - dampingFactor) */,
-          X(g_->X.p), Y(g_->Y.p) {}
+          X(g_->X.p), Y(g_->Y.p), Zc(g_->vf ? g_->Z0.p : nullptr), Zn(g_->vf ? g_->Z1.p : nullptr) {}
 
     // fresh = Model ctor (rank = n at the seed, 0 elsewhere);  !fresh = X already holds a caller-supplied rank vector
     // (Model.deliverRanks called on its own): no frontier knowledge, and the binade scan only if those ranks are >= 0
@@ -788,6 +872,8 @@ struct GroupIter {
         hipStream_t s = g->stream;
         const size_t elems = (size_t)tg * (size_t)n * G;
         if (fresh) RWR_HIP(hipMemsetAsync(X, 0, elems * sizeof(double), s));
+        if (fresh && Zc) RWR_HIP(hipMemsetAsync(Zc, 0, elems * sizeof(double), s));
+        if (!fresh && Zc) hipLaunchKernelGGL(k_make_z, dim3(cdiv(elems, 256)), dim3(256), 0, s, (int64_t)elems, G, X, Zc, g->w_src.p, c1);
         // frontier bitmaps for the first iterations (chunked SpMM only)
         static const int nz_iters_env = [] { const char *e = getenv("RWR_NZ_ITERS"); return e ? atoi(e) : 4; }();
         static const int spmm_variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
@@ -801,14 +887,14 @@ struct GroupIter {
         // single exact seed (lane-per-row SpMV): row-level skipping only, for exactly those iterations
         // (on multi-million-node sparse graphs a single seed's 3-hop frontier is still worth marking: measured -7 % per call
         //  on the 6 M-node graph, +10 % on the 0.6 M-node one)
-        if (G == 1 && tg == 1 && act_env < 0 && act_iters == 2 && g->n >= 2000000) act_iters = 3;
+        if (G == 1 && tg == 1 && act_env < 0 && act_iters == 2 && g->n >= spmv_big_n()) act_iters = 3;
         if (G == 1 && tg == 1 && spmm_variant != 0 && g->nonneg) nz_iters = act_iters;
         if (!fresh) nz_iters = act_iters = 0;
         const size_t nzw = ((size_t)n + 31) / 32;
         nz_cur = nz_iters > 0 ? g->d_nz.p : nullptr;
         nz_oth = nz_iters > 0 ? g->d_nz.p + (size_t)tg * nzw : nullptr;
         if (nz_cur) RWR_HIP(hipMemsetAsync(nz_cur, 0, (size_t)tg * nzw * sizeof(uint32_t), s));
-        if (fresh) hipLaunchKernelGGL(k_init_seeds, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, X, d_seeds, nz_cur);
+        if (fresh) hipLaunchKernelGGL(k_init_seeds, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, X, d_seeds, nz_cur, Zc, g->w_src.p, c1);
         RWR_HIP(hipGetLastError());
         it = 0;
         // Seed-row chain of the dense iterations.  The role-specialised fold (k_seed_chain_roles) takes ~20 cycles per
@@ -827,10 +913,13 @@ struct GroupIter {
         scan = g->opts.mode != RWR_MODE_FAST && c1 >= 0.0 && c1 <= 1.0 && g->nonneg && ranks_nonneg &&
                (chain_kind == 2 || (chain_kind == 1 && (double)tg * G * per_seed < scan_work));
         if (scan) RWR_TRY(chain_scan_prepare(g, G, tg, d_seeds, s));
+        // (the simple one-lane reference kernel of the seed row walks the weighted in-lists itself)
+        if (Zc && g->opts.mode != RWR_MODE_FAST && chain_kind == 0 && !scan) RWR_TRY(ensure_in_w(g));
         return RWR_OK;
     }
 
-    int32_t step(EvPool &pool, std::vector<hipEvent_t> &spmm_ev, std::vector<hipEvent_t> &chain_ev)
+    // last = no further step follows: the value-free path need not form the next z
+    int32_t step(EvPool &pool, std::vector<hipEvent_t> &spmm_ev, std::vector<hipEvent_t> &chain_ev, bool last = false)
     {
         const int32_t n = g->n;
         hipStream_t s = g->stream, s2 = g->stream2;
@@ -855,7 +944,7 @@ struct GroupIter {
         const bool scan_now = exact && scan && (!act || G == 1);
         if (scan_now) {
             // parallel chain on the main stream, ahead of the SpMM (which skips the seed rows)
-            RWR_DISPATCH_G(G, launch_seed_terms<GG>(g, tg, X, d_seeds, c1, d_evoff, s));
+            RWR_DISPATCH_G(G, launch_seed_terms<GG>(g, tg, X, d_seeds, c1, d_evoff, s, Zc));
             hipEvent_t c0 = nullptr, c1e = nullptr;
             if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, s)); }
             RWR_TRY(chain_scan_step(g, G, tg, X, Y, d_seeds, d_evoff, c1, nz_out, s));
@@ -863,7 +952,7 @@ struct GroupIter {
             s2 = s;
         } else if (exact) {
             // fork: the seed-row chain runs beside the SpMM on the second stream
-            RWR_DISPATCH_G(G, launch_seed_terms<GG>(g, tg, X, d_seeds, c1, d_evoff, s));
+            RWR_DISPATCH_G(G, launch_seed_terms<GG>(g, tg, X, d_seeds, c1, d_evoff, s, Zc));
             gate_it = (use_gate && s2 != s) ? g->d_gate.p + (it % GATE_SLOTS) : nullptr;
             if (gate_it) RWR_HIP(hipMemsetAsync(gate_it, 0, sizeof(unsigned int), s));
             RWR_HIP(hipEventRecord(g->ev_fork, s));
@@ -885,15 +974,20 @@ struct GroupIter {
         }
         hipEvent_t a = nullptr, b = nullptr;
         if (prof) { a = pool.get(); b = pool.get(); RWR_HIP(hipEventRecord(a, s)); }
-        RWR_DISPATCH_G(G, launch_spmm<GG>(g, tg, X, Y, d_seeds, c1, exact ? 1 : 0, nz_in, nz_out, s, act));
-        if (prof) { RWR_HIP(hipEventRecord(b, s)); spmm_ev.push_back(a); spmm_ev.push_back(b); }
+        double *zout = (Zc && !last) ? Zn : nullptr;
+        RWR_DISPATCH_G(G, launch_spmm<GG>(g, tg, X, Y, d_seeds, c1, exact ? 1 : 0, nz_in, nz_out, s, act, Zc, zout));
+        if (prof) { RWR_HIP(hipEventRecord(b, s)); spmm_ev.push_back(a); spmm_ev.push_back(b); g->spmm_ev_dense.push_back(nz_in ? 0 : 1); }
+        if (!nz_in) { g->stats.spmm_dense_launches += 1; ++dense_steps; }
         if (exact) {
             if (s2 != s && !scan_now) RWR_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
         } else {
             RWR_DISPATCH_G(G, launch_restart_final<GG>(g, tg, Y, d_seeds, nz_out, s));
         }
+        // value-free path: the seed rows' own z, now that the seed-row kernel has left their rank in Y
+        if (zout) hipLaunchKernelGGL(k_seed_z, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, Y, zout, d_seeds, g->w_src.p, c1);
         RWR_HIP(hipGetLastError());
         { double *t = X; X = Y; Y = t; }   // Model.updateRanks (Model.cs:103-108)
+        { double *t = Zc; Zc = Zn; Zn = t; }
         { uint32_t *tz = nz_cur; nz_cur = nz_oth; nz_oth = tz; }
         g->stats.spmm_launches += 1;
         g->stats.chain_launches += 1;
@@ -904,12 +998,13 @@ struct GroupIter {
 
 int32_t iterate_group(rwr_graph *g, int G, int tg, const int32_t *d_seeds, const int64_t *d_evoff, double d,
                       int64_t n_iter, double **final_X, EvPool &pool, std::vector<hipEvent_t> &spmm_ev,
-                      std::vector<hipEvent_t> &chain_ev)
+                      std::vector<hipEvent_t> &chain_ev, int64_t *dense_steps)
 {
     GroupIter gi(g, G, tg, d_seeds, d_evoff, d);
     RWR_TRY(gi.init());
-    for (int64_t it = 0; it < n_iter; ++it) RWR_TRY(gi.step(pool, spmm_ev, chain_ev));
+    for (int64_t it = 0; it < n_iter; ++it) RWR_TRY(gi.step(pool, spmm_ev, chain_ev, it + 1 == n_iter));
     *final_X = gi.X;
+    *dense_steps = gi.dense_steps;
     return RWR_OK;
 }
 
@@ -921,11 +1016,12 @@ static int32_t ensure_workspace(rwr_graph *g, int G, int32_t K, int *TG_out)
     if (cap == 0) {
         size_t fr = 0, tot = 0;
         RWR_HIP(hipMemGetInfo(&fr, &tot));
-        // what is already held by X/Y counts as available
-        fr += (g->X.count + g->Y.count) * sizeof(double);
-        cap = fr / 2;
+        // what is already held by the rank matrices counts as available
+        fr += (g->X.count + g->Y.count + g->Z0.count + g->Z1.count) * sizeof(double);
+        cap = fr / 2 + fr / 4;
     }
-    const size_t per_tile = 2 * n * (size_t)G * sizeof(double);
+    const size_t mats = g->vf ? 4 : 2;   // X, Y (+ the value-free path's z of the current and of the next ranks)
+    const size_t per_tile = mats * n * (size_t)G * sizeof(double);
     int TG = g->opts.tile_group > 0 ? g->opts.tile_group : (int)(cap / (per_tile ? per_tile : 1));
     if (TG < 1) TG = 1;
     if (TG > ntiles) TG = ntiles;
@@ -934,6 +1030,10 @@ static int32_t ensure_workspace(rwr_graph *g, int G, int32_t K, int *TG_out)
     if (g->opts.mode != RWR_MODE_FAST && g->opts.tile_group <= 0 && TG > 192) TG = 192;
     RWR_TRY(g->X.ensure((size_t)TG * n * G));
     RWR_TRY(g->Y.ensure((size_t)TG * n * G));
+    if (g->vf) {
+        RWR_TRY(g->Z0.ensure((size_t)TG * n * G));
+        RWR_TRY(g->Z1.ensure((size_t)TG * n * G));
+    }
     RWR_TRY(g->d_seeds.ensure((size_t)ntiles * G));
     RWR_TRY(g->d_part.ensure((size_t)TG * RP_GRID * G));
     RWR_TRY(g->d_nz.ensure(3 * (size_t)TG * ((n + 31) / 32)));   // X, Y non-zero rows + active destination rows
@@ -1005,6 +1105,11 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
                   "NaN, or the explicit weights of a node sum to 0 or overflow); rwr_model_run accepts such graphs");
         return RWR_E_UNSUPPORTED;
     }
+    if (!(d >= 0.0 && d <= 1.0)) {
+        // outside [0, 1] ranks go negative (or NaN): the exclusion marker and the ranking keys assume scores >= 0
+        set_error("Recommendation needs a damping factor in [0, 1] (got %g); rwr_model_run accepts any value", d);
+        return RWR_E_UNSUPPORTED;
+    }
     for (int32_t k = 0; k < K; ++k)
         if (seeds[k] < 0 || seeds[k] >= n) {
             set_error("seed %d (batch position %d) is outside [0, %d)", seeds[k], k, n);
@@ -1022,8 +1127,9 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
     if (any_dangling) { seeds = live_seeds.data(); K = (int32_t)live_seeds.size(); }
     hipStream_t s = g->stream;
     const size_t out_all = (size_t)K_all * (size_t)top_n;
-    RWR_TRY(g->d_out_id.ensure(out_all + 64 * (size_t)top_n));
-    RWR_TRY(g->d_out_score.ensure(out_all + 64 * (size_t)top_n));
+    // (every emitter indexes these tables by the caller's batch position < K_all: no padding rows are ever written)
+    RWR_TRY(g->d_out_id.ensure(out_all + 64));
+    RWR_TRY(g->d_out_score.ensure(out_all + 64));
     RWR_TRY(g->d_counts.ensure((size_t)K_all + 64));
     // output tables are indexed by the caller's batch position (K_all rows)
     RWR_HIP(hipMemsetAsync(g->d_out_id.p, 0, out_all * sizeof(int64_t), s));
@@ -1060,17 +1166,20 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
     EvPool pool;
     std::vector<hipEvent_t> spmm_ev, chain_ev, rank_ev, iter_ev;
     const bool prof = g->opts.profile != 0;
+    g->spmm_ev_dense.clear();
     for (int t0 = 0; t0 < ntiles; t0 += TG) {
         const int tg = (ntiles - t0 < TG) ? (ntiles - t0) : TG;
         const int32_t *dseeds = g->d_seeds.p + (size_t)t0 * G;
         double *Xf = nullptr;
         hipEvent_t i0 = nullptr, i1 = nullptr;
         if (prof) { i0 = pool.get(); i1 = pool.get(); RWR_HIP(hipEventRecord(i0, s)); }
-        RWR_TRY(iterate_group(g, G, tg, dseeds, g->d_evoff.p + (size_t)t0 * G, d, n_iter, &Xf, pool, spmm_ev, chain_ev));
+        int64_t dense_steps = 0;
+        RWR_TRY(iterate_group(g, G, tg, dseeds, g->d_evoff.p + (size_t)t0 * G, d, n_iter, &Xf, pool, spmm_ev, chain_ev, &dense_steps));
         if (prof) { RWR_HIP(hipEventRecord(i1, s)); iter_ev.push_back(i0); iter_ev.push_back(i1); }
         int32_t real = 0;
         for (size_t q = (size_t)t0 * G; q < (size_t)(t0 + tg) * G; ++q) real += slot_k[q] >= 0;
         g->stats.spmm_seed_steps += (int64_t)real * n_iter;
+        g->stats.spmm_dense_seed_steps += (int64_t)real * dense_steps;
         hipEvent_t a = nullptr, b = nullptr;
         if (prof) { a = pool.get(); b = pool.get(); RWR_HIP(hipEventRecord(a, s)); }
         hipLaunchKernelGGL(k_exclude, dim3((unsigned)(tg * G)), dim3(64), 0, s, n, tg, G, g->rowptr.p,
@@ -1103,6 +1212,12 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
     for (int32_t k = 0; k < K_all; ++k) counts[k] = hc[k];
     if (prof) RWR_TRY(chain_scan_collect(g, s));
     if (prof) {
+        for (size_t i = 0; i + 1 < spmm_ev.size(); i += 2)
+            if (i / 2 < g->spmm_ev_dense.size() && g->spmm_ev_dense[i / 2]) {
+                float ms = 0.f;
+                RWR_HIP(hipEventElapsedTime(&ms, spmm_ev[i], spmm_ev[i + 1]));
+                g->stats.spmm_dense_ms += ms;
+            }
         RWR_TRY(drain_events(spmm_ev, &g->stats.spmm_ms));
         RWR_TRY(drain_events(chain_ev, &g->stats.chain_ms));
         RWR_TRY(drain_events(rank_ev, &g->stats.rank_ms));
@@ -1202,6 +1317,7 @@ int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double
     RWR_TRY(g->d_part.ensure(RED_GRID + 8));
     double *part = g->d_part.p, *scalar = g->d_part.p + RED_GRID;
     int64_t done = 0;
+    bool converged = false;
     double *Xf = nullptr;
 
     if (seed >= 0) {
@@ -1221,7 +1337,7 @@ int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double
                 double diff = 0;
                 RWR_HIP(hipMemcpyAsync(&diff, scalar, sizeof(double), hipMemcpyDeviceToHost, s));
                 RWR_HIP(hipStreamSynchronize(s));
-                if (diff < threshold) break;
+                if (diff < threshold) { converged = true; break; }
                 a.clear(); b.clear(); pool.used = 0;                        // (synchronised above: safe to recycle)
             }
         }
@@ -1230,6 +1346,7 @@ int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double
         // global model (Model.cs:14-31): rank = 1, restart = 1/n.  Every row receives the restart mass of every node,
         // interleaved in node order in the reference; here: edge part in reference order + (tree-summed mass)/n.
         // Tolerance parity only.
+        RWR_TRY(ensure_in_w(g));   // (the global model runs the weighted kernels)
         double *X = g->X.p, *Y = g->Y.p;
         const double c1 = 1 - d, inv_n = 1.0 / n;
         hipLaunchKernelGGL(k_fill, dim3(cdiv((size_t)n, 256)), dim3(256), 0, s, X, n, 1.0);
@@ -1249,12 +1366,12 @@ int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double
                 double diff = 0;
                 RWR_HIP(hipMemcpyAsync(&diff, scalar, sizeof(double), hipMemcpyDeviceToHost, s));
                 RWR_HIP(hipStreamSynchronize(s));
-                if (diff < threshold) break;
+                if (diff < threshold) { converged = true; break; }
             }
         }
         Xf = X;
     }
-    if (!by_count && done >= max_iters) {
+    if (!by_count && !converged) {
         set_error("rwr_model_run: no convergence within %lld iterations (RWR_MAX_ITERS)", (long long)max_iters);
         return RWR_E_UNSUPPORTED;
     }
@@ -1293,6 +1410,7 @@ int32_t model_deliver(rwr_graph *g, int32_t seed, double d, const double *rank_i
         RWR_HIP(hipStreamSynchronize(g->stream2));
         out = gi.X;                                   // (step() swapped: X holds nextRank)
     } else {
+        RWR_TRY(ensure_in_w(g));
         RWR_TRY(g->d_part.ensure(RED_GRID + 8));
         double *part = g->d_part.p, *scalar = g->d_part.p + RED_GRID;
         const double c1 = 1 - d, inv_n = 1.0 / n;
@@ -1364,6 +1482,7 @@ int32_t part_begin(rwr_graph *g, int32_t lo, int32_t hi, const int32_t *seeds, i
         if (seeds[k] < 0 || seeds[k] >= n) { set_error("seed %d is outside [0, %d)", seeds[k], n); return RWR_E_RANGE; }
     int G = 1;
     while (G < K) G <<= 1;
+    RWR_TRY(ensure_in_w(g));   // (the slab step runs the weighted kernels on the caller's rank matrix)
     g->part_lo = lo; g->part_hi = hi; g->part_G = G; g->part_K = K; g->part_c1 = 1 - d;
     g->part_seeds.assign((size_t)G, -1);
     for (int32_t k = 0; k < K; ++k) g->part_seeds[k] = seeds[k];

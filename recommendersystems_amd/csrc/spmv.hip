@@ -17,11 +17,24 @@ typedef int v4i_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
 // (bid, nblk): this workgroup's index and the number of workgroups serving the bin -- the four bins share ONE launch
 // (k_spmv_exact_binned below), so that their tails overlap instead of queueing behind each other
+// VF (all bodies): value-free form (engine.h: rwr_graph::vf) -- x is then the z vector, z[i] = ((1-d) x[i]) * w_src[i],
+// the product Model.cs:84,87 forms for every link of source i; no weights are read, the row's sum is the list-order sum
+// of the gathered z, and the row's own z for the next step goes to zout (null on the last step).
+#define RWR_SPMV_STORE(J, ACC)                                                          \
+    {                                                                                   \
+        if ((J) != my_seed) {                                                           \
+            y[(J)] = (ACC);                                                             \
+            if (VF && zout) { const double rw__ = c1 * (ACC); zout[(J)] = rw__ * w_src[(J)]; } \
+        }                                                                               \
+        if (nz_out && (ACC) != 0.0) atomicOr(&nz_out[(uint32_t)(J) >> 5], 1u << ((J) & 31)); \
+    }
+template <bool VF>
 __device__ __forceinline__ void spmv_exact_lane(int bid, int nblk, int32_t r0, int32_t n, const int64_t *__restrict__ in_ptr,
                                                 const int32_t *__restrict__ in_src, const double *__restrict__ in_w,
                                                 const int32_t *__restrict__ row_order, const double *__restrict__ x,
                                                 double *__restrict__ y, int32_t my_seed, double c1,
-                                                const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
+                                                const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out,
+                                                const double *__restrict__ w_src, double *__restrict__ zout)
 {
     const int64_t stride = (int64_t)nblk * blockDim.x;
     for (int64_t r = (int64_t)r0 + (int64_t)bid * blockDim.x + threadIdx.x; r < n; r += stride) {
@@ -34,21 +47,28 @@ __device__ __forceinline__ void spmv_exact_lane(int bid, int nblk, int32_t r0, i
         for (; p + 8 <= e; p += 8) {
             const v4i_u i0 = *reinterpret_cast<const v4i_u *>(in_src + p);
             const v4i_u i1 = *reinterpret_cast<const v4i_u *>(in_src + p + 4);
-            const v2d_u w0 = *reinterpret_cast<const v2d_u *>(in_w + p);
-            const v2d_u w1 = *reinterpret_cast<const v2d_u *>(in_w + p + 2);
-            const v2d_u w2 = *reinterpret_cast<const v2d_u *>(in_w + p + 4);
-            const v2d_u w3 = *reinterpret_cast<const v2d_u *>(in_w + p + 6);
-            const double x0 = x[i0.x], x1 = x[i0.y], x2 = x[i0.z], x3 = x[i0.w];
-            const double x4 = x[i1.x], x5 = x[i1.y], x6 = x[i1.z], x7 = x[i1.w];
-            double rw;
-            rw = c1 * x0; acc += rw * w0.x;      // Model.cs:84,87 -- in list order
-            rw = c1 * x1; acc += rw * w0.y;
-            rw = c1 * x2; acc += rw * w1.x;
-            rw = c1 * x3; acc += rw * w1.y;
-            rw = c1 * x4; acc += rw * w2.x;
-            rw = c1 * x5; acc += rw * w2.y;
-            rw = c1 * x6; acc += rw * w3.x;
-            rw = c1 * x7; acc += rw * w3.y;
+            if (VF) {
+                const double x0 = x[i0.x], x1 = x[i0.y], x2 = x[i0.z], x3 = x[i0.w];
+                const double x4 = x[i1.x], x5 = x[i1.y], x6 = x[i1.z], x7 = x[i1.w];
+                acc += x0; acc += x1; acc += x2; acc += x3;     // z of the sources, in list order
+                acc += x4; acc += x5; acc += x6; acc += x7;
+            } else {
+                const v2d_u w0 = *reinterpret_cast<const v2d_u *>(in_w + p);
+                const v2d_u w1 = *reinterpret_cast<const v2d_u *>(in_w + p + 2);
+                const v2d_u w2 = *reinterpret_cast<const v2d_u *>(in_w + p + 4);
+                const v2d_u w3 = *reinterpret_cast<const v2d_u *>(in_w + p + 6);
+                const double x0 = x[i0.x], x1 = x[i0.y], x2 = x[i0.z], x3 = x[i0.w];
+                const double x4 = x[i1.x], x5 = x[i1.y], x6 = x[i1.z], x7 = x[i1.w];
+                double rw;
+                rw = c1 * x0; acc += rw * w0.x;      // Model.cs:84,87 -- in list order
+                rw = c1 * x1; acc += rw * w0.y;
+                rw = c1 * x2; acc += rw * w1.x;
+                rw = c1 * x3; acc += rw * w1.y;
+                rw = c1 * x4; acc += rw * w2.x;
+                rw = c1 * x5; acc += rw * w2.y;
+                rw = c1 * x6; acc += rw * w3.x;
+                rw = c1 * x7; acc += rw * w3.y;
+            }
         }
         {   // the last (up to 7) entries: all loads issued before the first dependent add
             const int cnt = (int)(e - p);
@@ -57,16 +77,18 @@ __device__ __forceinline__ void spmv_exact_lane(int bid, int nblk, int32_t r0, i
 #pragma unroll
             for (int u = 0; u < 7; ++u) {
                 ti[u] = u < cnt ? in_src[p + u] : 0;
-                tw[u] = u < cnt ? in_w[p + u] : 0.0;
+                tw[u] = (!VF && u < cnt) ? in_w[p + u] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < 7; ++u) tx[u] = u < cnt ? x[ti[u]] : 0.0;
 #pragma unroll
             for (int u = 0; u < 7; ++u)
-                if (u < cnt) { const double rw = c1 * tx[u]; acc += rw * tw[u]; }
+                if (u < cnt) {
+                    if (VF) acc += tx[u];
+                    else { const double rw = c1 * tx[u]; acc += rw * tw[u]; }
+                }
         }
-        if (j != my_seed) y[j] = acc;
-        if (nz_out && acc != 0.0) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
+        RWR_SPMV_STORE(j, acc)
     }
 }
 
@@ -82,11 +104,13 @@ __device__ __forceinline__ double readlane_f64(double v, int t)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), t);
     return __hiloint2double(hi, lo);
 }
+template <bool VF>
 __device__ __forceinline__ void spmv_exact_wave(int bid, int nblk, int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
                                                 const int32_t *__restrict__ in_src, const double *__restrict__ in_w,
                                                 const int32_t *__restrict__ row_order, const double *__restrict__ x,
                                                 double *__restrict__ y, int32_t my_seed, double c1,
-                                                const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
+                                                const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out,
+                                                const double *__restrict__ w_src, double *__restrict__ zout)
 {
     // the 64 products of a round are parked in LDS (double-buffered per wave); every lane then reads them back one by
     // one from the SAME address (a broadcast read, no bank conflict) -- one LDS read + one add per entry, and the reads
@@ -110,15 +134,15 @@ __device__ __forceinline__ void spmv_exact_wave(int bid, int nblk, int32_t r0, i
         double acc = 0.0;
         double cur = 0.0;
         if (p + lane < e) {
-            const double rw = c1 * x[in_src[p + lane]];
-            cur = rw * in_w[p + lane];
+            if (VF) cur = x[in_src[p + lane]];
+            else { const double rw = c1 * x[in_src[p + lane]]; cur = rw * in_w[p + lane]; }
         }
         while (p < e) {
             const int64_t pn = p + WAVE;
             double nxt = 0.0;
             if (pn + lane < e) {                       // issued ahead of the dependent adds below
-                const double rw = c1 * x[in_src[pn + lane]];
-                nxt = rw * in_w[pn + lane];
+                if (VF) nxt = x[in_src[pn + lane]];
+                else { const double rw = c1 * x[in_src[pn + lane]]; nxt = rw * in_w[pn + lane]; }
             }
             pb[buf][lane] = cur;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -134,10 +158,7 @@ __device__ __forceinline__ void spmv_exact_wave(int bid, int nblk, int32_t r0, i
             cur = nxt;
             p = pn;
         }
-        if (lane == 0) {
-            if (j != my_seed) y[j] = acc;
-            if (nz_out && acc != 0.0) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
-        }
+        if (lane == 0) RWR_SPMV_STORE(j, acc)
         j = jn; p = pn_; e = en_;
     }
 }
@@ -145,12 +166,13 @@ __device__ __forceinline__ void spmv_exact_wave(int bid, int nblk, int32_t r0, i
 // The same idea for shorter rows: W (16 or 4) lanes share a row, 64 / W rows per wave.  The W products of a round are
 // formed in parallel; every lane of the group then adds them in list order (the group's lanes all carry the row's
 // accumulator), taking product t from lane t of its group.
-template <int W>
+template <int W, bool VF>
 __device__ __forceinline__ void spmv_exact_group(int bid, int nblk, int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
                                                  const int32_t *__restrict__ in_src, const double *__restrict__ in_w,
                                                  const int32_t *__restrict__ row_order, const double *__restrict__ x,
                                                  double *__restrict__ y, int32_t my_seed, double c1,
-                                                 const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
+                                                 const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out,
+                                                 const double *__restrict__ w_src, double *__restrict__ zout)
 {
     constexpr int RPW = WAVE / W;
     const int lane = threadIdx.x & (WAVE - 1), gl = lane % W, grp = lane / W;
@@ -168,15 +190,15 @@ __device__ __forceinline__ void spmv_exact_group(int bid, int nblk, int32_t r0, 
         double acc = 0.0;
         double cur = 0.0;
         if (p + gl < e) {
-            const double rw = c1 * x[in_src[p + gl]];
-            cur = rw * in_w[p + gl];
+            if (VF) cur = x[in_src[p + gl]];
+            else { const double rw = c1 * x[in_src[p + gl]]; cur = rw * in_w[p + gl]; }
         }
         while (__any(p < e)) {
             const int64_t pn = p + W;
             double nxt = 0.0;
             if (pn + gl < e) {
-                const double rw = c1 * x[in_src[pn + gl]];
-                nxt = rw * in_w[pn + gl];
+                if (VF) nxt = x[in_src[pn + gl]];
+                else { const double rw = c1 * x[in_src[pn + gl]]; nxt = rw * in_w[pn + gl]; }
             }
             const int64_t left = e - p;
             const int cnt = left > W ? W : (left > 0 ? (int)left : 0);
@@ -188,15 +210,13 @@ __device__ __forceinline__ void spmv_exact_group(int bid, int nblk, int32_t r0, 
             cur = nxt;
             if (p < e) p = pn;
         }
-        if (gl == 0 && j >= 0) {
-            if (j != my_seed) y[j] = acc;
-            if (nz_out && acc != 0.0) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
-        }
+        if (gl == 0 && j >= 0) RWR_SPMV_STORE(j, acc)
     }
 }
 
 // rows [ra, b0): a wave per row; [b0, b1): 16 lanes per row; [b1, b2): 4 lanes per row; [b2, n): a lane per row.
 // Workgroups [0, nb0) serve the first bin, the next nb1 the second, ...
+template <bool VF>
 __global__ __launch_bounds__(256) void k_spmv_exact_binned(int nb0, int nb1, int nb2, int nb3, int32_t ra, int32_t b0, int32_t b1,
                                                            int32_t b2, int32_t n, const int64_t *__restrict__ in_ptr,
                                                            const int32_t *__restrict__ in_src,
@@ -204,17 +224,18 @@ __global__ __launch_bounds__(256) void k_spmv_exact_binned(int nb0, int nb1, int
                                                            const int32_t *__restrict__ row_order,
                                                            const double *__restrict__ x, double *__restrict__ y,
                                                            const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
-                                                           const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
+                                                           const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out,
+                                                           const double *__restrict__ w_src, double *__restrict__ zout)
 {
     const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
     int b = blockIdx.x;
-    if (b < nb0) { spmv_exact_wave(b, nb0, ra, b0, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out); return; }
+    if (b < nb0) { spmv_exact_wave<VF>(b, nb0, ra, b0, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out, w_src, zout); return; }
     b -= nb0;
-    if (b < nb1) { spmv_exact_group<16>(b, nb1, b0, b1, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out); return; }
+    if (b < nb1) { spmv_exact_group<16, VF>(b, nb1, b0, b1, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out, w_src, zout); return; }
     b -= nb1;
-    if (b < nb2) { spmv_exact_group<4>(b, nb2, b1, b2, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out); return; }
+    if (b < nb2) { spmv_exact_group<4, VF>(b, nb2, b1, b2, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out, w_src, zout); return; }
     b -= nb2;
-    spmv_exact_lane(b, nb3, b2, n, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out);
+    spmv_exact_lane<VF>(b, nb3, b2, n, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out, w_src, zout);
 }
 
 // K = 1, FAST mode: the classic vector-CSR SpMV.  W lanes share one destination row: each lane streams every W-th
@@ -223,12 +244,13 @@ __global__ __launch_bounds__(256) void k_spmv_exact_binned(int nb0, int nb1, int
 // bit-identical results, so structural ties stay tied.  The summation order differs from the reference's, which is
 // why this kernel exists only in FAST mode (scores within 1e-6).  Rows are binned by in-degree (row_order is sorted
 // by it): W = 64 / 16 / 4 / 1.
-template <int W>
+template <int W, bool VF>
 __global__ __launch_bounds__(256) void k_spmv_vector(int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
                                                      const int32_t *__restrict__ in_src,
                                                      const double *__restrict__ in_w,
                                                      const int32_t *__restrict__ row_order,
-                                                     const double *__restrict__ x, double *__restrict__ y, double c1)
+                                                     const double *__restrict__ x, double *__restrict__ y, double c1,
+                                                     const double *__restrict__ w_src, double *__restrict__ zout)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int l = (int)(gid % W);
@@ -238,27 +260,40 @@ __global__ __launch_bounds__(256) void k_spmv_vector(int32_t r0, int32_t r1, con
         double acc = 0.0;
         int64_t p = p0 + l;
         for (; p + 3 * W < p1; p += 4 * W) {               // four independent gathers in flight per lane
-            const double a0 = c1 * x[in_src[p]], a1 = c1 * x[in_src[p + W]];
-            const double a2 = c1 * x[in_src[p + 2 * W]], a3 = c1 * x[in_src[p + 3 * W]];
-            acc += a0 * in_w[p];
-            acc += a1 * in_w[p + W];
-            acc += a2 * in_w[p + 2 * W];
-            acc += a3 * in_w[p + 3 * W];
+            if (VF) {
+                const double a0 = x[in_src[p]], a1 = x[in_src[p + W]], a2 = x[in_src[p + 2 * W]], a3 = x[in_src[p + 3 * W]];
+                acc += a0; acc += a1; acc += a2; acc += a3;
+            } else {
+                const double a0 = c1 * x[in_src[p]], a1 = c1 * x[in_src[p + W]];
+                const double a2 = c1 * x[in_src[p + 2 * W]], a3 = c1 * x[in_src[p + 3 * W]];
+                acc += a0 * in_w[p];
+                acc += a1 * in_w[p + W];
+                acc += a2 * in_w[p + 2 * W];
+                acc += a3 * in_w[p + 3 * W];
+            }
         }
-        for (; p < p1; p += W) acc += (c1 * x[in_src[p]]) * in_w[p];
+        for (; p < p1; p += W) {
+            if (VF) acc += x[in_src[p]];
+            else acc += (c1 * x[in_src[p]]) * in_w[p];
+        }
 #pragma unroll
         for (int off = W / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, W);
-        if (l == 0) y[j] = acc;
+        if (l == 0) {
+            y[j] = acc;
+            if (VF && zout) { const double rw = c1 * acc; zout[j] = rw * w_src[j]; }
+        }
     }
 }
 
 // very long rows (in-degree >= 2048): a whole 1024-thread workgroup per row; per-lane partials, shuffle butterfly per
 // wave, then the 16 wave sums are staged in LDS and added in wave order
+template <bool VF>
 __global__ __launch_bounds__(1024) void k_spmv_row_block(int32_t r1, const int64_t *__restrict__ in_ptr,
                                                          const int32_t *__restrict__ in_src,
                                                          const double *__restrict__ in_w,
                                                          const int32_t *__restrict__ row_order,
-                                                         const double *__restrict__ x, double *__restrict__ y, double c1)
+                                                         const double *__restrict__ x, double *__restrict__ y, double c1,
+                                                         const double *__restrict__ w_src, double *__restrict__ zout)
 {
     __shared__ double wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -268,14 +303,22 @@ __global__ __launch_bounds__(1024) void k_spmv_row_block(int32_t r1, const int64
         double acc = 0.0;
         int64_t p = p0 + tid;
         for (; p + 3 * 1024 < p1; p += 4 * 1024) {
-            const double a0 = c1 * x[in_src[p]], a1 = c1 * x[in_src[p + 1024]];
-            const double a2 = c1 * x[in_src[p + 2048]], a3 = c1 * x[in_src[p + 3072]];
-            acc += a0 * in_w[p];
-            acc += a1 * in_w[p + 1024];
-            acc += a2 * in_w[p + 2048];
-            acc += a3 * in_w[p + 3072];
+            if (VF) {
+                const double a0 = x[in_src[p]], a1 = x[in_src[p + 1024]], a2 = x[in_src[p + 2048]], a3 = x[in_src[p + 3072]];
+                acc += a0; acc += a1; acc += a2; acc += a3;
+            } else {
+                const double a0 = c1 * x[in_src[p]], a1 = c1 * x[in_src[p + 1024]];
+                const double a2 = c1 * x[in_src[p + 2048]], a3 = c1 * x[in_src[p + 3072]];
+                acc += a0 * in_w[p];
+                acc += a1 * in_w[p + 1024];
+                acc += a2 * in_w[p + 2048];
+                acc += a3 * in_w[p + 3072];
+            }
         }
-        for (; p < p1; p += 1024) acc += (c1 * x[in_src[p]]) * in_w[p];
+        for (; p < p1; p += 1024) {
+            if (VF) acc += x[in_src[p]];
+            else acc += (c1 * x[in_src[p]]) * in_w[p];
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
         if (lane == 0) wsum[wv] = acc;
@@ -284,22 +327,36 @@ __global__ __launch_bounds__(1024) void k_spmv_row_block(int32_t r1, const int64
             double t = 0.0;
             for (int q = 0; q < 16; ++q) t += wsum[q];
             y[j] = t;
+            if (VF && zout) { const double rw = c1 * t; zout[j] = rw * w_src[j]; }
         }
         __syncthreads();
     }
 }
 
-void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hipStream_t s)
+void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hipStream_t s, const double *zin, double *zout)
 {
     const int32_t n = g->n, bh = g->bin_huge, b0 = g->bin_end[0], b1 = g->bin_end[1], b2 = g->bin_end[2];
-    if (bh > 0)
-        hipLaunchKernelGGL(k_spmv_row_block, dim3(bh < 4096 ? bh : 4096), dim3(1024), 0, s, bh, g->in_ptr.p, g->in_src.p,
-                           g->in_w.p, g->row_order.p, x, y, c1);
+    const bool vf = zin != nullptr;
+    const double *gs = vf ? zin : x;       // gather source
     auto grid = [](int64_t rows, int W) { int64_t blocks = (rows * W + 255) / 256; return (unsigned)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks)); };
-    if (b0 > bh) hipLaunchKernelGGL(k_spmv_vector<64>, dim3(grid(b0 - bh, 64)), dim3(256), 0, s, bh, b0, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, x, y, c1);
-    if (b1 > b0) hipLaunchKernelGGL(k_spmv_vector<16>, dim3(grid(b1 - b0, 16)), dim3(256), 0, s, b0, b1, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, x, y, c1);
-    if (b2 > b1) hipLaunchKernelGGL(k_spmv_vector<4>, dim3(grid(b2 - b1, 4)), dim3(256), 0, s, b1, b2, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, x, y, c1);
-    if (n > b2) hipLaunchKernelGGL(k_spmv_vector<1>, dim3(grid(n - b2, 1)), dim3(256), 0, s, b2, n, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, x, y, c1);
+#define RWR_VEC(KERN, GRID, BLOCK, ...)                                                                      \
+    {                                                                                                        \
+        if (vf) hipLaunchKernelGGL((KERN<true>), GRID, BLOCK, 0, s, __VA_ARGS__, g->w_src.p, zout);          \
+        else hipLaunchKernelGGL((KERN<false>), GRID, BLOCK, 0, s, __VA_ARGS__, g->w_src.p, zout);            \
+    }
+#define RWR_VECW(W, GRID, ...)                                                                                           \
+    {                                                                                                                    \
+        if (vf) hipLaunchKernelGGL((k_spmv_vector<W, true>), GRID, dim3(256), 0, s, __VA_ARGS__, g->w_src.p, zout);      \
+        else hipLaunchKernelGGL((k_spmv_vector<W, false>), GRID, dim3(256), 0, s, __VA_ARGS__, g->w_src.p, zout);        \
+    }
+    if (bh > 0)
+        RWR_VEC(k_spmv_row_block, dim3(bh < 4096 ? bh : 4096), dim3(1024), bh, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, gs, y, c1)
+    if (b0 > bh) RWR_VECW(64, dim3(grid(b0 - bh, 64)), bh, b0, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, gs, y, c1)
+    if (b1 > b0) RWR_VECW(16, dim3(grid(b1 - b0, 16)), b0, b1, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, gs, y, c1)
+    if (b2 > b1) RWR_VECW(4, dim3(grid(b2 - b1, 4)), b1, b2, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, gs, y, c1)
+    if (n > b2) RWR_VECW(1, dim3(grid(n - b2, 1)), b2, n, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, gs, y, c1)
+#undef RWR_VEC
+#undef RWR_VECW
 }
 
 // EXACT single seed: two phases (ITEM rows, then the others -- engine.h: row_order_x), each binned by in-degree:
@@ -307,14 +364,16 @@ void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hip
 // (RWR_GROUP_ROWS = 0 keeps everything under 128 on the lane-per-row form; RWR_ROW_ORDER != 0 or RWR_SPMV_PHASES = 0: one
 // pass in row_order).  One launch per phase.
 void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *seeds, double c1, int skip,
-                       const uint32_t *act, uint32_t *nz_out, hipStream_t s)
+                       const uint32_t *act, uint32_t *nz_out, hipStream_t s, const double *zin, double *zout)
 {
     static const bool by_degree = [] { const char *e = getenv("RWR_ROW_ORDER"); return !e || atoi(e) == 0; }();
     static const int group_rows = [] { const char *e = getenv("RWR_GROUP_ROWS"); return e ? atoi(e) : 2; }();
     // two phases pay once the rank vector no longer fits the L2s (measured: -17 % SpMV time on the 6 M-node graph, nothing on
     // the 0.6 M-node one, +10 % on the dense 0.2 M-node one, where the second launch only adds a tail)
     static const int phases_env = [] { const char *e = getenv("RWR_SPMV_PHASES"); return e ? atoi(e) : -1; }();
-    const int phases = phases_env >= 0 ? phases_env : (g->n >= 2000000 ? 1 : 0);
+    const int phases = phases_env >= 0 ? phases_env : (g->n >= spmv_big_n() ? 1 : 0);
+    const bool vf = zin != nullptr;
+    const double *gs = vf ? zin : X;       // gather source
     auto blocks_for = [](int64_t rows, int W) { const int64_t b = (rows * W + 255) / 256; return (int)(b < 0 ? 0 : (b > 16384 ? 16384 : b)); };
     auto launch = [&](const int32_t *order, int32_t ra, int32_t rows, const int32_t bins[3]) {
         if (rows <= 0) return;
@@ -323,9 +382,13 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
         const int32_t b2 = (by_degree && group_rows >= 2) ? ra + bins[2] : b1;
         const int32_t rend = ra + rows;
         const int nb0 = blocks_for(b0 - ra, 64), nb1 = blocks_for(b1 - b0, 16), nb2 = blocks_for(b2 - b1, 4), nb3 = blocks_for(rend - b2, 1);
-        if (nb0 + nb1 + nb2 + nb3 > 0)
-            hipLaunchKernelGGL(k_spmv_exact_binned, dim3((unsigned)(nb0 + nb1 + nb2 + nb3)), dim3(256), 0, s, nb0, nb1, nb2, nb3, ra, b0,
-                               b1, b2, rend, g->in_ptr.p, g->in_src.p, g->in_w.p, order, X, Y, seeds, c1, skip, act, nz_out);
+        if (nb0 + nb1 + nb2 + nb3 <= 0) return;
+        if (vf)
+            hipLaunchKernelGGL(k_spmv_exact_binned<true>, dim3((unsigned)(nb0 + nb1 + nb2 + nb3)), dim3(256), 0, s, nb0, nb1, nb2, nb3, ra, b0,
+                               b1, b2, rend, g->in_ptr.p, g->in_src.p, g->in_w.p, order, gs, Y, seeds, c1, skip, act, nz_out, g->w_src.p, zout);
+        else
+            hipLaunchKernelGGL(k_spmv_exact_binned<false>, dim3((unsigned)(nb0 + nb1 + nb2 + nb3)), dim3(256), 0, s, nb0, nb1, nb2, nb3, ra, b0,
+                               b1, b2, rend, g->in_ptr.p, g->in_src.p, g->in_w.p, order, gs, Y, seeds, c1, skip, act, nz_out, g->w_src.p, zout);
     };
     if (by_degree && phases) {
         launch(g->row_order_x.p, 0, g->x_rows[0], g->x_bins[0]);
