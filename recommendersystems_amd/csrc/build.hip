@@ -299,7 +299,7 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     g->nonneg = h_flags[3] ? 0 : 1;
     static const int vf_env = [] { const char *e = getenv("RWR_VALUE_FREE"); return e ? atoi(e) : 1; }();
     g->vf = (g->uniform && g->nonneg && vf_env) ? 1 : 0;
-    RWR_TRY(g->in_src.ensure((size_t)nnz));
+    RWR_TRY(g->in_src.ensure((size_t)nnz + 64));   // (padded: spmv_blocked.hip fetches up to 48 indices ahead of a row's end)
     if (g->vf) g->in_w.release();
     else RWR_TRY(g->in_w.ensure((size_t)nnz));
     if (nnz > 0) {
@@ -371,6 +371,9 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     g->stats.nnz = g->nnz;
     g->stats.uniform = g->uniform;
     g->stats.uniform_path = g->vf;
+    g->bk_state = 0;              // the blocked single-seed SpMV re-decides (and rebuilds its tables) on first use
+    g->bk_border.release();
+    g->bk_bp.release();
     return RWR_OK;
 }
 

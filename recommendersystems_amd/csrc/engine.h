@@ -59,6 +59,12 @@ struct rwr_graph {
     rwr::DevBuf<int32_t> item_order;  // ITEM rows by id descending
     rwr::DevBuf<int32_t> item_rows;   // ITEM rows by row index ascending
 
+    // single-seed SpMV on dense graphs with z staged through LDS (spmv_blocked.hip): 0 = not decided yet, 1 = tables built,
+    // -1 = this graph does not qualify; re-decided after every (re)build
+    int32_t bk_state = 0, bk_nblk = 0, bk_nhub = 0, bk_ngroups = 0, bk_nwg = 0;
+    rwr::DevBuf<int32_t> bk_border;   // rows: hub rows by in-degree descending, then the others likewise
+    rwr::DevBuf<int32_t> bk_bp;       // [nblk + 1][n]: entries of row border[pos] whose source is below the block's first node
+
     // batch workspace (lazily sized)
     rwr::DevBuf<double> X, Y;         // rank matrices [tile][n][G]
     rwr::DevBuf<double> Z0, Z1;       // value-free path: z = ((1-d) x) * w_src of the current / next ranks, same layout
@@ -137,6 +143,11 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
                        double *zout = nullptr);
 void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hipStream_t s, const double *zin = nullptr,
                         double *zout = nullptr);
+// spmv_blocked.hip: single-seed SpMV of dense value-free graphs, z staged through LDS block by block (bitwise the same sums)
+int32_t blocked_prepare(rwr_graph *g);
+bool blocked_ready(const rwr_graph *g);
+void launch_spmv_blocked(rwr_graph *g, const double *zin, double *Y, double *zout, const int32_t *seeds, int skip, double c1,
+                         bool fast, hipStream_t s);
 // chain_scan.hip: the exact seed-row chain as a parallel binade scan
 int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, hipStream_t s);
 int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,

@@ -231,6 +231,75 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
     }
 }
 
+// Value-free, dense steps, V = 2 seeds per lane: every row gather is a 16-byte load (global_load_dwordx4), G / 2 lanes
+// share a destination row and a wave serves 128 / G rows at once -- half the vector-memory instructions and address
+// computations of the 8-byte form for the same bytes.  Same sums, same order: lane (row, k) owns seeds 2k and 2k+1.
+typedef double v2d_a __attribute__((ext_vector_type(2), aligned(16)));
+template <int G>
+__global__ __launch_bounds__(256) void k_spmm_vf_wide(int32_t n, const int64_t *__restrict__ in_ptr,
+                                                      const int32_t *__restrict__ in_src,
+                                                      const int32_t *__restrict__ row_order,
+                                                      const double *__restrict__ Z, double *__restrict__ Y,
+                                                      const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
+                                                      const double *__restrict__ w_src, double *__restrict__ Zout)
+{
+    static_assert(G >= 16 && G <= 64, "wide SpMM needs 16 <= G <= 64");
+    constexpr int L = G / 2;                 // lanes per destination row
+    constexpr int RPW = WAVE / L;            // rows per wave
+    constexpr int CH = L < 16 ? L : 16;      // entries per chunk = 16-byte gathers in flight per lane
+    const int tile = blockIdx.y;
+    const size_t toff = (size_t)tile * (size_t)n * G;
+    Z += toff;
+    Y += toff;
+    if (Zout) Zout += toff;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int sub = lane / L, k = lane % L;
+    const int gbase = (lane - k) << 2;
+    const int32_t seed0 = skip_seed_row ? seeds[tile * G + 2 * k] : -1;
+    const int32_t seed1 = skip_seed_row ? seeds[tile * G + 2 * k + 1] : -1;
+    const int wpb = blockDim.x / WAVE;
+    const int64_t nwaves = (int64_t)gridDim.x * wpb;
+    for (int64_t rb = ((int64_t)blockIdx.x * wpb + threadIdx.x / WAVE) * RPW; rb < n; rb += nwaves * RPW) {
+        const int64_t r = rb + sub;
+        int32_t j = -1;
+        int64_t p = 0, e = 0;
+        if (r < n) {
+            j = row_order[r];
+            p = in_ptr[j];
+            e = in_ptr[j + 1];
+        }
+        double a0 = 0.0, a1 = 0.0;
+        while (__any(p < e)) {
+            const int64_t left = e - p;
+            const int cnt = left > CH ? CH : (left > 0 ? (int)left : 0);
+            const int32_t my_idx = (k < cnt) ? in_src[p + k] : 0;
+            v2d_a xv[CH];
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int idx = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), my_idx);
+                if (t < cnt) xv[t] = *reinterpret_cast<const v2d_a *>(Z + (size_t)idx * G + 2 * k);
+                else xv[t] = v2d_a{0.0, 0.0};
+            }
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                if (t < cnt) { a0 += xv[t].x; a1 += xv[t].y; }     // the sources' z (Model.cs:84,87), list order
+            }
+            p += cnt;
+        }
+        if (j >= 0) {
+            const size_t at = (size_t)j * G + 2 * k;
+            const double ws = w_src[j];
+            if (j != seed0 && j != seed1) {
+                *reinterpret_cast<v2d_a *>(Y + at) = v2d_a{a0, a1};
+                if (Zout) { const double r0 = c1 * a0, r1 = c1 * a1; *reinterpret_cast<v2d_a *>(Zout + at) = v2d_a{r0 * ws, r1 * ws}; }
+            } else {
+                if (j != seed0) { Y[at] = a0; if (Zout) { const double r0 = c1 * a0; Zout[at] = r0 * ws; } }
+                if (j != seed1) { Y[at + 1] = a1; if (Zout) { const double r1 = c1 * a1; Zout[at + 1] = r1 * ws; } }
+            }
+        }
+    }
+}
+
 // First iterations: destination rows that can become non-zero = out-neighbours (explicit links) of the rows of X
 // that hold a non-zero.  One thread per bitmap word of the tile; pushes over the RAW out-links.
 __global__ __launch_bounds__(256) void k_mark_active(int32_t n, const uint32_t *__restrict__ nz, uint32_t *__restrict__ act,
@@ -704,6 +773,17 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
             return;
         }
     }
+    if constexpr (G >= 16) {
+        // dense value-free steps: 16-byte gathers (two seeds per lane)
+        static const int wide = [] { const char *e = getenv("RWR_SPMM_WIDE"); return e ? atoi(e) : 0; }();
+        if (vf && wide && variant != 0 && !nz_in && !nz_out && !act) {
+            constexpr int RPW2 = WAVE / (G / 2);
+            const unsigned want2 = cdiv((size_t)g->n, (size_t)RPW2 * 4);
+            hipLaunchKernelGGL(k_spmm_vf_wide<G>, dim3(want2 < 8192u ? want2 : 8192u, tg), dim3(256), 0, s, g->n, g->in_ptr.p,
+                               g->in_src.p, g->row_order.p, GS, Y, seeds, c1, skip, g->w_src.p, Zout);
+            return;
+        }
+    }
     if constexpr (G >= 8) {
         if (variant != 0) {
 #define RWR_SPMM_LAUNCH3(CH, CHK, WR, VFF)                                                                         \
@@ -913,6 +993,7 @@ struct GroupIter {
         scan = g->opts.mode != RWR_MODE_FAST && c1 >= 0.0 && c1 <= 1.0 && g->nonneg && ranks_nonneg &&
                (chain_kind == 2 || (chain_kind == 1 && (double)tg * G * per_seed < scan_work));
         if (scan) RWR_TRY(chain_scan_prepare(g, G, tg, d_seeds, s));
+        if (Zc && G == 1 && tg == 1) RWR_TRY(blocked_prepare(g));   // single seed on a dense graph: LDS-blocked SpMV
         // (the simple one-lane reference kernel of the seed row walks the weighted in-lists itself)
         if (Zc && g->opts.mode != RWR_MODE_FAST && chain_kind == 0 && !scan) RWR_TRY(ensure_in_w(g));
         return RWR_OK;

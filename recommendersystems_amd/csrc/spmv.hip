@@ -337,6 +337,10 @@ void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hip
 {
     const int32_t n = g->n, bh = g->bin_huge, b0 = g->bin_end[0], b1 = g->bin_end[1], b2 = g->bin_end[2];
     const bool vf = zin != nullptr;
+    if (vf && blocked_ready(g)) {          // dense graph: z staged through LDS (spmv_blocked.hip)
+        launch_spmv_blocked(g, zin, y, zout, nullptr, 0, c1, true, s);
+        return;
+    }
     const double *gs = vf ? zin : x;       // gather source
     auto grid = [](int64_t rows, int W) { int64_t blocks = (rows * W + 255) / 256; return (unsigned)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks)); };
 #define RWR_VEC(KERN, GRID, BLOCK, ...)                                                                      \
@@ -373,6 +377,10 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
     static const int phases_env = [] { const char *e = getenv("RWR_SPMV_PHASES"); return e ? atoi(e) : -1; }();
     const int phases = phases_env >= 0 ? phases_env : (g->n >= spmv_big_n() ? 1 : 0);
     const bool vf = zin != nullptr;
+    if (vf && !act && !nz_out && blocked_ready(g)) {   // dense step of a dense graph: z staged through LDS (spmv_blocked.hip)
+        launch_spmv_blocked(g, zin, Y, zout, seeds, skip, c1, g->opts.mode == RWR_MODE_FAST && !skip, s);
+        return;
+    }
     const double *gs = vf ? zin : X;       // gather source
     auto blocks_for = [](int64_t rows, int W) { const int64_t b = (rows * W + 255) / 256; return (int)(b < 0 ? 0 : (b > 16384 ? 16384 : b)); };
     auto launch = [&](const int32_t *order, int32_t ra, int32_t rows, const int32_t bins[3]) {

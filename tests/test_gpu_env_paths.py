@@ -31,7 +31,10 @@ def run_child(env_extra):
     {"RWR_VALUE_FREE": "0"},
     {"RWR_BIG_N": "100", "RWR_SPMV_PHASES": "1", "RWR_ACT_ITERS": "3"},
     {"RWR_BIG_N": "100", "RWR_VALUE_FREE": "0"},
+    {"RWR_SPMV_BLOCKED": "1"},
     {"RWR_SPMM": "0"},
+    {"RWR_SPMM_WIDE": "1"},
+    {"RWR_SPMM_WIDE": "1", "RWR_BIG_N": "100"},
     {"RWR_CHAIN": "0"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_env_selected_paths_match_the_oracle(env):

@@ -1,0 +1,31 @@
+"""Event-timed single-seed SpMV (dense steps) on one configuration: `python tools/k1_time.py C3 [exact|fast]`.
+Prints one line: per-launch time of the dense SpMV steps and the wall time of the call.  Experiment knobs come from the
+environment (read once per process by librwr), so A/B runs are separate invocations."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from recommendersystems_amd import synth                                  # noqa: E402
+from recommendersystems_amd.rwr_based import Graph, Recommender           # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
+mode = sys.argv[2] if len(sys.argv) > 2 else "exact"
+no, U, I, E, K = synth.CONFIGS[cfg]
+g = synth.bipartite(no, U, I, E)
+flat = {k: g[k] for k in ("node_id", "node_type", "rowptr", "dst", "etype", "w")}
+G = Graph.from_flat(**flat, profile=True, mode=mode)
+G.buildGraph()
+rec = Recommender(G)
+seed = U // 2
+rec.Recommendation(seed, 0.15, 10, 100)
+G.reset_stats()
+reps = 5
+t = time.perf_counter()
+for _ in range(reps):
+    rec.Recommendation(seed, 0.15, 10, 100)
+wall = (time.perf_counter() - t) / reps
+st = G.stats()
+tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("RWR_"))
+print(f"{cfg} {mode} [{tag}] dense SpMV {st['spmm_dense_ms'] / max(st['spmm_dense_launches'], 1) * 1e3:.1f} us/launch "
+      f"({st['spmm_dense_launches']} launches), call {wall * 1e3:.2f} ms", flush=True)
