@@ -203,6 +203,7 @@ int32_t rwr_graph_destroy(rwr_graph *g)
     if (g->ev_b) (void)hipEventDestroy(g->ev_b);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
+    if (g->sm_pin) (void)hipHostFree(g->sm_pin);
     delete g;
     return RWR_OK;
 }
@@ -255,13 +256,19 @@ int32_t rwr_recommend(rwr_graph *g, int32_t seed, float d, int32_t n_iter, int32
     // the ranked list stays on the device until its length is known, then goes straight into the caller's arrays
     // (no host staging copy: the full list of a 5 M-item graph is 80 MB)
     int32_t cnt = 0;
+    g->sm_pin_count = -1;
     RWR_TRY(recommend_batch(g, &seed, 1, (double)d, n_iter, (int32_t)width, nullptr, nullptr, &cnt, width));
     if (*inout_count < cnt || ((!out_id || !out_score) && cnt > 0)) {
         set_error("rwr_recommend: output holds %lld entries, %d needed", (long long)*inout_count, cnt);
         *inout_count = cnt;
         return RWR_E_CAPACITY;
     }
-    if (cnt > 0) {
+    if (cnt > 0 && g->sm_pin_count == cnt) {
+        // ego-network-sized graph (small.hip): the kernel wrote the list into pinned host memory
+        const int64_t *pin_id = reinterpret_cast<const int64_t *>(g->sm_pin);
+        memcpy(out_id, pin_id, sizeof(int64_t) * (size_t)cnt);
+        memcpy(out_score, pin_id + 4096, sizeof(double) * (size_t)cnt);
+    } else if (cnt > 0) {
         RWR_HIP(hipMemcpyAsync(out_id, g->d_out_id.p, sizeof(int64_t) * (size_t)cnt, hipMemcpyDeviceToHost, g->stream));
         RWR_HIP(hipMemcpyAsync(out_score, g->d_out_score.p, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, g->stream));
         RWR_HIP(hipStreamSynchronize(g->stream));

@@ -67,6 +67,9 @@ struct rwr_graph {
 
     // batch workspace (lazily sized)
     rwr::DevBuf<double> X, Y;         // rank matrices [tile][n][G]
+    rwr::DevBuf<int32_t> sm_tab;      // small.hip: places of the seed row's addends (per call)
+    void *sm_pin = nullptr;           // small.hip: pinned host buffer the one-launch kernel writes the ranked list into
+    int32_t sm_pin_count = -1;        // >= 0: the last single-seed call left its list (that many entries) in sm_pin
     rwr::DevBuf<double> Z0, Z1;       // value-free path: z = ((1-d) x) * w_src of the current / next ranks, same layout
     rwr::DevBuf<int32_t> d_seeds;     // [tile][G], -1 = padding lane
     rwr::DevBuf<int32_t> d_slot_k;    // [tile][G]: batch position of the seed in this slot (-1 = padding)
@@ -148,6 +151,10 @@ int32_t blocked_prepare(rwr_graph *g);
 bool blocked_ready(const rwr_graph *g);
 void launch_spmv_blocked(rwr_graph *g, const double *zin, double *Y, double *zout, const int32_t *seeds, int skip, double c1,
                          bool fast, hipStream_t s);
+// small.hip: ego-network-sized graphs, one single-seed Recommendation as ONE kernel launch (bitwise the EXACT path's result)
+bool small_path_ok(const rwr_graph *g);
+int32_t recommend_small(rwr_graph *g, int32_t seed, double d, int32_t n_iter, int32_t top_n, int64_t *ids, double *scores,
+                        int32_t *count);
 // chain_scan.hip: the exact seed-row chain as a parallel binade scan
 int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, hipStream_t s);
 int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,

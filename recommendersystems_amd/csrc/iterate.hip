@@ -1196,6 +1196,13 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
             set_error("seed %d (batch position %d) is outside [0, %d)", seeds[k], k, n);
             return RWR_E_RANGE;
         }
+    if (K == 1 && small_path_ok(g)) {
+        // ego-network-sized graph, one seed (the unmodified harness's call, Experiment.cs:109): the whole call is one launch
+        RWR_TRY(recommend_small(g, seeds[0], d, n_iter, top_n, ids, scores, counts));
+        g->stats.seeds_done += 1;
+        g->stats.total_wall_ms += now_ms() - t_begin;
+        return RWR_OK;
+    }
     // dangling seeds (no explicit out-link) are answered directly (see k_emit_dangling); the rest is iterated
     const int32_t K_all = K;
     std::vector<int32_t> live_seeds, live_rows, dang_seeds, dang_rows;

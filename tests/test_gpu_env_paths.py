@@ -5,7 +5,9 @@ process (tests/env_child.py) and compared with the C restatement of the referenc
   (Graph.cs:79-81, Model.cs:84-88: the product fl(fl((1-d) rank[i]) * weight) is the same double for every link of i);
 * the "graph beyond the L2s" paths -- two-phase row order of the single-seed SpMV, three frontier iterations, FAST single
   seed on the list-order kernels, 32-seed tiles -- which the default threshold only selects from 2 M nodes on (the 100 M-like
-  headline configuration): RWR_BIG_N lowers the threshold so that oracle-sized graphs run them."""
+  headline configuration): RWR_BIG_N lowers the threshold so that oracle-sized graphs run them;
+* the general single-seed path on ego-network-sized graphs (RWR_SMALL=0), which by default take the one-launch kernel of
+  small.hip -- both must equal the oracle bit for bit."""
 import os
 import subprocess
 import sys
@@ -32,6 +34,8 @@ def run_child(env_extra):
     {"RWR_BIG_N": "100", "RWR_SPMV_PHASES": "1", "RWR_ACT_ITERS": "3"},
     {"RWR_BIG_N": "100", "RWR_VALUE_FREE": "0"},
     {"RWR_SPMV_BLOCKED": "1"},
+    {"RWR_SMALL": "0"},
+    {"RWR_SMALL": "0", "RWR_VALUE_FREE": "0"},
     {"RWR_SPMM": "0"},
     {"RWR_SPMM_WIDE": "1"},
     {"RWR_SPMM_WIDE": "1", "RWR_BIG_N": "100"},
