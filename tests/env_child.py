@@ -44,6 +44,14 @@ def graphs():
     for name, (no, U, I, E) in {"dense-2-blocks": (7, 3000, 9000, 400_000), "dense-3-blocks": (8, 4000, 16500, 600_000)}.items():
         sg = synth.bipartite(no, U, I, E)
         yield name, {k: sg[k] for k in ("node_id", "node_type", "rowptr", "dst", "etype", "w")}, True
+    # 80 user rows of ~900 links each: the build's long-row path (build.hip: 64 rows holding more than 8 tiles of links),
+    # with weights that differ inside a row and UNDEFINED links in between (general weighted kernels)
+    sg = synth.bipartite(11, 80, 3000, 80_000)
+    rng = np.random.default_rng(3)
+    lg = {k: sg[k] for k in ("node_id", "node_type", "rowptr", "dst", "etype", "w")}
+    lg["w"] = rng.choice([0.5, 1.0, 2.0, 3.25], size=len(lg["w"]))
+    lg["etype"] = np.where(rng.random(len(lg["etype"])) < 0.1, 0, 1).astype(np.uint8)
+    yield "long-rows-weighted", lg, False
     yield "mixed-weights", gg.random_graph(11, n_users=700, n_items=2500, n_likes=20000, n_etc=20, n_friend=800,
                                            n_mention=500, n_author=300), False
 
