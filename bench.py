@@ -289,9 +289,10 @@ def dry_run(args, rank, world):
 
 
 def bench_row_partitioned(args, rank, local_rank, world, flat, U, I, g, n, nnz):
-    """Config 5 shape: every rank owns a slab of source rows; one step = one batch of K (<= 64) seeds for the WHOLE job;
-    per iteration one all-reduce(sum) of the n x G rank matrix over RCCL.  "scaling": "strong" (the batch is fixed,
-    the matrix is split).  Tolerance parity (partial sums re-associate)."""
+    """Config 5 shape: every rank owns a slab of source rows; one step = one batch of K seeds for the WHOLE job; per
+    iteration one reduce-scatter(sum) of the partial n x G rank matrix by slabs over RCCL (a rank only reads its own slab
+    again; the last iteration all-reduces, ranking needs every row).  "scaling": "strong" (the batch is fixed, the matrix
+    is split).  Tolerance parity (partial sums re-associate)."""
     import torch
     import torch.distributed as dist
     from recommendersystems_amd import synth
@@ -328,8 +329,11 @@ def bench_row_partitioned(args, rank, local_rank, world, flat, U, I, g, n, nnz):
                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{args.config} row-partitioned x{world}: {U} users x {I} items, {g['likes']} likes, "
                                       f"{K} seeds for the whole job, T={T_ITER}, top_n={TOP_N}",
-                          "parallelism": f"source-row slabs x{world}, all-reduce of the {n}x{G} rank matrix per iteration",
-                          "exchange_bytes_per_iteration": n * G * 8},
+                          "parallelism": f"source-row slabs x{world}, reduce-scatter of the {n}x{G} partial rank matrix per "
+                                         f"iteration (all-reduce on the last one)",
+                          "exchange_payload_bytes_per_iteration": n * G * 8,
+                          "exchange_note": "reduce-scatter: each rank sends (world-1)/world of the payload once; the "
+                                           "round-1 all-reduce moved twice that, plus a second collective for the restart scalars"},
                "roofline": {"bound": "hbm", "achieved": T_ITER * step_bytes * args.steps / elapsed / 1e9,
                             "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                             "frac": T_ITER * step_bytes * args.steps / elapsed / 1e9 / (HBM_PEAK_GBPS * world),

@@ -240,6 +240,15 @@ int32_t rwr_model_deliver(rwr_graph *g, int32_t seed, double d, const double *ra
  * Recommender.cs:20-24) and reports counts[k] = -1 for the others. */
 int32_t rwr_part_begin(rwr_graph *g, int32_t slab_lo, int32_t slab_hi, const int32_t *seeds, int32_t K, double d,
                        void *dev_x, int32_t *tile_seeds_out);
+/* The preferred step: ONE asynchronous call per iteration, enqueued on the CALLER's HIP stream (`stream` = a hipStream_t,
+ * e.g. the stream torch.distributed / RCCL is ordered after; NULL = the device's default stream, which is what
+ * torch.cuda.current_stream() denotes unless the caller switched streams) with no host synchronisation:
+ *     y = (1-d) * P_slab^T x  over ALL n rows,  then  y[seed_k][k] += restart mass of the slab's rows  (Model.cs:91-93,96-97)
+ * so that the sum over the ranks of y is the complete next rank matrix.  A rank only ever READS its own slab of x (its
+ * graph holds out-links of its own rows only), so the exchange is a REDUCE-SCATTER of y by slabs -- half the bytes of an
+ * all-reduce, and no second collective for the restart scalars; only the last step needs every row everywhere (ranking)
+ * and uses an all-reduce.  recommendersystems_amd/partitioned.py is the host logic. */
+int32_t rwr_part_step(rwr_graph *g, const void *dev_x, void *dev_y, void *stream);
 int32_t rwr_part_local_step(rwr_graph *g, const void *dev_x, void *dev_y, void *dev_r);
 int32_t rwr_part_finish_step(rwr_graph *g, void *dev_y, const void *dev_r);
 int32_t rwr_part_rank(rwr_graph *g, void *dev_x, int32_t top_n, int64_t *ids, double *scores, int32_t *counts);

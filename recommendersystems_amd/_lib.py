@@ -20,7 +20,7 @@ EXPORTS = [
     "rwr_version", "rwr_device_count", "rwr_last_error",
     "rwr_graph_create", "rwr_graph_update_links", "rwr_graph_destroy", "rwr_graph_size", "rwr_graph_get_normalized",
     "rwr_recommend", "rwr_recommend_eval", "rwr_recommend_batch", "rwr_model_run", "rwr_model_deliver",
-    "rwr_part_begin", "rwr_part_local_step", "rwr_part_finish_step", "rwr_part_rank",
+    "rwr_part_begin", "rwr_part_step", "rwr_part_local_step", "rwr_part_finish_step", "rwr_part_rank",
     "rwr_get_stats", "rwr_reset_stats",
 ]
 
@@ -94,6 +94,8 @@ def load():
                                    p(C.c_int32)]
     lib.rwr_part_local_step.restype = C.c_int32
     lib.rwr_part_local_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rwr_part_step.restype = C.c_int32
+    lib.rwr_part_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rwr_part_finish_step.restype = C.c_int32
     lib.rwr_part_finish_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rwr_part_rank.restype = C.c_int32

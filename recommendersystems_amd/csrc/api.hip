@@ -343,6 +343,14 @@ int32_t rwr_part_local_step(rwr_graph *g, const void *dev_x, void *dev_y, void *
     return part_local_step(g, (const double *)dev_x, (double *)dev_y, (double *)dev_r);
 }
 
+int32_t rwr_part_step(rwr_graph *g, const void *dev_x, void *dev_y, void *stream)
+{
+    g_err[0] = 0;
+    if (!g || !dev_x || !dev_y || dev_x == dev_y) { set_error("rwr_part_step: NULL or aliasing argument"); return RWR_E_INVALID; }
+    RWR_BIND(g);
+    return part_step(g, (const double *)dev_x, (double *)dev_y, (hipStream_t)stream);
+}
+
 int32_t rwr_part_finish_step(rwr_graph *g, void *dev_y, const void *dev_r)
 {
     g_err[0] = 0;

@@ -134,6 +134,7 @@ int32_t eval_ranked(rwr_graph *g, int32_t cnt, const int64_t *test_sorted_host, 
 int32_t part_begin(rwr_graph *g, int32_t lo, int32_t hi, const int32_t *seeds, int32_t K, double d, double *x,
                    int32_t *G_out);
 int32_t part_local_step(rwr_graph *g, const double *x, double *y, double *r);
+int32_t part_step(rwr_graph *g, const double *x, double *y, hipStream_t stream);
 int32_t part_finish_step(rwr_graph *g, double *y, const double *r);
 int32_t part_rank(rwr_graph *g, double *x, int32_t top_n, int64_t *ids, double *scores, int32_t *counts);
 int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double value, double *rank_out,

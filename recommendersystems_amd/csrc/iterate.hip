@@ -1575,7 +1575,7 @@ int32_t part_begin(rwr_graph *g, int32_t lo, int32_t hi, const int32_t *seeds, i
     g->part_seeds.assign((size_t)G, -1);
     for (int32_t k = 0; k < K; ++k) g->part_seeds[k] = seeds[k];
     RWR_TRY(g->d_seeds.ensure(G));
-    RWR_TRY(g->d_part.ensure((size_t)RP_GRID * G));
+    RWR_TRY(g->d_part.ensure((size_t)RP_GRID * G + G));
     RWR_HIP(hipMemcpy(g->d_seeds.p, g->part_seeds.data(), G * sizeof(int32_t), hipMemcpyHostToDevice));
     hipStream_t s = g->stream;
     RWR_HIP(hipMemsetAsync(x, 0, (size_t)n * G * sizeof(double), s));
@@ -1599,6 +1599,24 @@ int32_t part_local_step(rwr_graph *g, const double *x, double *y, double *r)
     RWR_DISPATCH_G(G, launch_spmm<GG>(g, 1, x, y, g->d_seeds.p, c1, 0, nullptr, nullptr, s));
     RWR_HIP(hipGetLastError());
     RWR_HIP(hipStreamSynchronize(s));
+    return RWR_OK;
+}
+
+// One whole local step on the caller's stream, no host synchronisation: partial y over all rows, plus this slab's restart
+// mass at the seeds' rows -- the sum over the ranks of y is then the next rank matrix (include/rwr.h: rwr_part_step).
+int32_t part_step(rwr_graph *g, const double *x, double *y, hipStream_t stream)
+{
+    const int G = g->part_G;
+    if (G == 0) { set_error("rwr_part_step: rwr_part_begin has not been called"); return RWR_E_INVALID; }
+    hipStream_t s = stream;                              // exactly the caller's stream (NULL = the device's default stream)
+    const double c1 = g->part_c1;
+    double *r = g->d_part.p + (size_t)RP_GRID * G;       // (behind the per-block partials)
+    RWR_DISPATCH_G(G, hipLaunchKernelGGL(k_slab_restart_partial<GG>, dim3(RP_GRID), dim3(RP_BLOCK), 0, s, g->part_lo,
+                                         g->part_hi, g->dangling.p, x, g->d_part.p, c1));
+    hipLaunchKernelGGL(k_slab_restart_final, dim3(1), dim3(64), 0, s, G, RP_GRID, g->d_part.p, r);
+    RWR_DISPATCH_G(G, launch_spmm<GG>(g, 1, x, y, g->d_seeds.p, c1, 0, nullptr, nullptr, s));
+    hipLaunchKernelGGL(k_part_add_restart, dim3(1), dim3(64), 0, s, G, y, r, g->d_seeds.p);
+    RWR_HIP(hipGetLastError());
     return RWR_OK;
 }
 

@@ -7,10 +7,14 @@ Two regimes:
   of the batch.  NO data-path collective; `gather_seed_shards` only collects the small result tables.
 
 * row partition (graph beyond one GPU, config 5): the transition matrix is split by SOURCE rows into contiguous
-  slabs balanced by link count; every power-iteration step ends with an all-reduce(sum) of the partial rank matrix
-  and of the restart mass.  This is the one real exchange step of the path.  An ADDITION to the reference (which
-  has no distributed mode); parity with the single-GPU result is to tolerance, not bitwise (partial sums
-  re-associate).
+  slabs balanced by link count.  A rank computes a partial next rank matrix over ALL rows from its slab of the
+  current one (plus its slab's restart mass, added locally at the seeds' rows), and since it will only ever READ
+  its own slab again, every power-iteration step ends with a REDUCE-SCATTER of the partial matrix by slabs -- half
+  the bytes of an all-reduce and no second collective for the restart scalars; only the last step all-reduces,
+  because ranking needs every row.  The step is enqueued asynchronously on the stream the collective runs on: no
+  host synchronisation inside the loop.  This is the one real exchange step of the path.  An ADDITION to the
+  reference (which has no distributed mode); parity with the single-GPU result is to tolerance, not bitwise
+  (partial sums re-associate).
 
 The compute backend is the HIP library (`HipSlabBackend`); tests inject a numpy stand-in to exercise this host
 logic on CPU with gloo.
@@ -115,6 +119,13 @@ class HipSlabBackend:
         assert g_out.value == G
         return x, y, r
 
+    def step(self, x, y):
+        """One whole local step (partial y over all rows + this slab's restart mass at the seeds' rows), enqueued on
+        torch's current stream -- the one the collective that follows is ordered after; no host synchronisation."""
+        stream = self.torch.cuda.current_stream(self.dev).cuda_stream
+        self._lib.check(self._lib.load().rwr_part_step(self.graph._handle(), C.c_void_p(x.data_ptr()),
+                                                       C.c_void_p(y.data_ptr()), C.c_void_p(stream)))
+
     def local_step(self, x, y, r):
         self.torch.cuda.synchronize()
         self._lib.check(self._lib.load().rwr_part_local_step(self.graph._handle(), C.c_void_p(x.data_ptr()),
@@ -142,6 +153,25 @@ class HipSlabBackend:
         return self.torch.from_numpy(a).to(self.dev)
 
 
+MAX_TILE = 64      # seeds per rank-matrix tile of the row-partitioned mode (rwr_part_begin)
+
+
+def reduce_scatter_slabs(t, G: int, bounds, rank: int, group=None):
+    """Reduce-scatter(sum) of the partial rank matrix t[n * G] by the (uneven) node slabs: afterwards rank r holds the
+    complete rows [bounds[r], bounds[r + 1]) of the sum in place; the rest of t is unspecified (never read again).
+    Uneven slabs = one reduce per destination rank (what an uneven NCCL reduce-scatter is made of; gloo has reduce too)."""
+    import torch.distributed as dist
+    world = len(bounds) - 1
+    works = []
+    for r in range(world):
+        lo, hi = int(bounds[r]) * G, int(bounds[r + 1]) * G
+        if hi > lo:
+            works.append(dist.reduce(t[lo:hi], dst=dist.get_global_rank(group, r) if group is not None else r,
+                                     group=group, async_op=True))
+    for w in works:
+        w.wait()
+
+
 class PartitionedRecommender:
     """Recommendation over a source-row-partitioned transition matrix (one slab per rank)."""
 
@@ -152,24 +182,39 @@ class PartitionedRecommender:
         local = slab_graph(flat, self.lo, self.hi)
         factory = backend_factory or HipSlabBackend
         self.backend = factory(local, self.lo, self.hi, **opts)
+        self.exchanged_bytes = 0          # payload handed to collectives by this rank (measurement)
 
     def _all_reduce(self, t):
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(t, group=self.group)      # sum; RCCL over xGMI on GPUs
 
+    def _reduce_scatter(self, t, G):
+        if self.world > 1:
+            reduce_scatter_slabs(t, G, self.bounds, self.rank, self.group)
+
     def RecommendationBatch(self, seeds, dampingFactor: float, nIteration: int, topN: int):
         """Same result (to tolerance) on every rank as Recommender.RecommendationBatch on one GPU.
-        dampingFactor crosses as float and is widened (Recommender.cs:14,16 -> Model.cs:33)."""
-        be = self.backend
+        dampingFactor crosses as float and is widened (Recommender.cs:14,16 -> Model.cs:33).  Batches beyond one tile
+        (64 seeds) are run tile after tile."""
         seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        if len(seeds) > MAX_TILE:
+            parts = [self.RecommendationBatch(seeds[i:i + MAX_TILE], dampingFactor, nIteration, topN)
+                     for i in range(0, len(seeds), MAX_TILE)]
+            return tuple(np.concatenate([p[j] for p in parts]) for j in range(3))
+        be = self.backend
         d = float(np.float32(dampingFactor))
-        x, y, r = be.begin(seeds, d)
-        for _ in range(int(nIteration)):
-            be.local_step(x, y, r)                      # y = (1-d) P_slab^T x,  r = slab's restart mass
-            self._all_reduce(be.to_exchange(y))         # the exchange step: n*G*8 bytes per iteration
-            self._all_reduce(be.to_exchange(r))
-            be.finish_step(y, r)                        # y[seed_k][k] += r[k]
+        x, y, _ = be.begin(seeds, d)
+        G = int(x.numel() // be.n)
+        T = int(nIteration)
+        for it in range(T):
+            be.step(x, y)                               # y = (1-d) P_slab^T x over all rows (+ own restart mass), asynchronous
+            ex = be.to_exchange(y)
+            if it + 1 == T:
+                self._all_reduce(ex)                    # last step: ranking needs every row on the seed's owner
+            else:
+                self._reduce_scatter(ex, G)             # a rank only reads ITS slab of x again: half an all-reduce
+            self.exchanged_bytes += int(ex.numel()) * 8
             x, y = y, x                                 # Model.updateRanks
         ids, sc, cnt = be.rank(x, topN)                 # owner ranks only; -1 elsewhere
         if self.world > 1:

@@ -35,6 +35,12 @@ class NumpySlabBackend:
         rr = np.where(dang, X[sl], X[sl] - self.c1 * X[sl])
         r[:] = torch.from_numpy(rr.sum(axis=0))
 
+    def step(self, x, y):
+        # partial y over all rows + this slab's restart mass at the seeds' rows (rwr_part_step)
+        r = torch.zeros(len(self.seeds), dtype=torch.float64)
+        self.local_step(x, y, r)
+        self.finish_step(y, r)
+
     def finish_step(self, y, r):
         K = len(self.seeds)
         y.view(self.n, K)[self.seeds, np.arange(K)] += r

@@ -1,6 +1,6 @@
 """Two processes sharing the one GPU of the test box (gloo for the process group; RCCL needs one GPU per rank): the
 real HIP backends under the multi-process host logic -- seed-sharded batch + result gather, and the row-partitioned
-iteration with its per-step all-reduce."""
+iteration with its per-step reduce-scatter (all-reduce on the last step)."""
 import os
 import socket
 
@@ -53,6 +53,15 @@ def _worker(rank, world, port, q):
             dist.all_reduce(h)
             t.copy_(h)
         pr._all_reduce = via_host
+
+        def rs_via_host(t, G):                       # reduce-scatter by slabs; everything outside the own slab poisoned
+            h = t.cpu()
+            pt.reduce_scatter_slabs(h, G, pr.bounds, rank)
+            keep = h[pr.lo * G:pr.hi * G].clone()
+            h.fill_(float("nan"))
+            h[pr.lo * G:pr.hi * G] = keep
+            t.copy_(h)
+        pr._reduce_scatter = rs_via_host
         ids, sc, cnt = pr.RecommendationBatch(seeds, 0.15, 10, 12)
         pi, ps, pc = F.recommend_batch(seeds, 0.15, 10, 12)
         ok2 = bool((ids == pi).all() and (cnt == pc).all() and np.abs(sc - ps).max() <= 1e-9)

@@ -268,9 +268,10 @@ def test_global_model_tolerance(amd, case):
 
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_row_partitioned_logical_ranks(amd, world):
-    """BASELINE config 5 on ONE device: `world` logical ranks, each with the HIP slab backend (rwr_part_*),
-    partials summed in rank order in place of the RCCL all-reduce.  Tolerance parity (partial sums re-associate):
-    identical top-k lists, scores within 1e-9 of the oracle."""
+    """BASELINE config 5 on ONE device: `world` logical ranks, each with the HIP slab backend (rwr_part_step),
+    partials summed in rank order in place of the RCCL reduce-scatter (every rank gets ITS slab of the sum; the rest of
+    its buffer is poisoned with NaN).  Tolerance parity (partial sums re-associate): identical top-k lists, scores within
+    1e-9 of the oracle."""
     import torch
     from recommendersystems_amd import partitioned as pt
     g = gg.random_graph(51, n_users=500, n_items=1800, n_likes=15000, n_etc=10, n_friend=500, n_mention=300,
@@ -281,20 +282,22 @@ def test_row_partitioned_logical_ranks(amd, world):
     bes = [pt.HipSlabBackend(pt.slab_graph(g, int(bounds[r]), int(bounds[r + 1])), int(bounds[r]), int(bounds[r + 1]))
            for r in range(world)]
     d = float(np.float32(0.15))
-    state = [be.begin(seeds, d) for be in bes]
-    for _ in range(10):
-        for be, (x, y, r) in zip(bes, state):
-            be.local_step(x, y, r)
-        ysum = torch.stack([st[1] for st in state]).sum(0)       # stands in for all-reduce(sum)
-        rsum = torch.stack([st[2] for st in state]).sum(0)
-        for st in state:
-            st[1].copy_(ysum)
-            st[2].copy_(rsum)
-        new_state = []
-        for be, (x, y, r) in zip(bes, state):
-            be.finish_step(y, r)
-            new_state.append((y, x, r))
-        state = new_state
+    state = [list(be.begin(seeds, d)[:2]) for be in bes]
+    G = state[0][0].numel() // len(g["node_id"])
+    T = 10
+    for it in range(T):
+        for be, (x, y) in zip(bes, state):
+            be.step(x, y)                                        # rwr_part_step: asynchronous, on torch's current stream
+        ysum = torch.stack([st[1] for st in state]).sum(0)       # what the collective delivers
+        for r, st in enumerate(state):
+            if it + 1 == T:
+                st[1].copy_(ysum)                                # last step: all-reduce (ranking needs every row)
+            else:                                                # reduce-scatter: a rank receives ITS slab only -- the rest
+                st[1].fill_(float("nan"))                        # of the buffer is poisoned to prove it is never read
+                lo, hi = int(bounds[r]) * G, int(bounds[r + 1]) * G
+                st[1][lo:hi] = ysum[lo:hi]
+            st[0], st[1] = st[1], st[0]
+    state = [(x, y, None) for x, y in state]
     oi, os_, oc = F.recommend_batch(seeds, 0.15, 10, 20)
     ids = np.zeros_like(oi); sc = np.zeros_like(os_); cnt = np.zeros_like(oc); owners = np.zeros(len(seeds), dtype=int)
     for be, (x, y, r) in zip(bes, state):
@@ -309,6 +312,10 @@ def test_row_partitioned_logical_ranks(amd, world):
         pr = pt.PartitionedRecommender(g)
         i2, s2, c2 = pr.RecommendationBatch(seeds, 0.15, 10, 20)
         assert (i2 == oi).all() and (c2 == oc).all() and np.abs(s2 - os_).max() <= 1e-9
+        many = (np.arange(150, dtype=np.int64) * 500 // 150).astype(np.int32)       # beyond one 64-seed tile
+        i3, s3, c3 = pr.RecommendationBatch(many, 0.15, 10, 20)
+        o3 = F.recommend_batch(many, 0.15, 10, 20)
+        assert (i3 == o3[0]).all() and (c3 == o3[2]).all() and np.abs(s3 - o3[1]).max() <= 1e-9
 
 
 def test_recommend_eval_bitwise(amd):

@@ -1,5 +1,6 @@
-"""N > 1 host path on CPU: world_size-2 gloo processes run the seed-sharded gather and the row-partitioned
-iteration (all-reduce exchange per step) with a numpy compute stand-in, and compare with the oracle."""
+"""N > 1 host path on CPU: world_size-2 / -3 gloo processes run the seed-sharded gather and the row-partitioned
+iteration (reduce-scatter of the partial rank matrix by slabs per step, all-reduce on the last one) with a numpy
+compute stand-in, and compare with the oracle."""
 import os
 import socket
 
@@ -55,11 +56,27 @@ def _worker(rank, world, port, q):
         g = gg.random_graph(**CASE)
         F = FlatGraph(**g)
         seeds = np.array([0, 3, 17, 41, 59], dtype=np.int32)
-        # (1) row-partitioned iteration with the all-reduce exchange
+        # (1) row-partitioned iteration: reduce-scatter by slabs every step, all-reduce on the last; whatever lies outside
+        #     a rank's own slab after a reduce-scatter is poisoned, to prove the next step never reads it
         pr = pt.PartitionedRecommender(g, rank=rank, world=world, backend_factory=NumpySlabBackend)
+        plain_rs = pr._reduce_scatter
+
+        def poisoning_rs(t, G):
+            plain_rs(t, G)
+            keep = t[pr.lo * G:pr.hi * G].clone()
+            t.fill_(float("nan"))
+            t[pr.lo * G:pr.hi * G] = keep
+        pr._reduce_scatter = poisoning_rs
         ids, sc, cnt = pr.RecommendationBatch(seeds, 0.15, 10, 12)
         oi, os_, oc = F.recommend_batch(seeds, 0.15, 10, 12)
         ok1 = bool((cnt == oc).all() and (ids == oi).all() and np.abs(sc - os_).max() <= 1e-9)
+        # exchange volume: T - 1 reduce-scatters + 1 all-reduce of the n x K matrix (an all-reduce moves twice that)
+        ok1 = ok1 and pr.exchanged_bytes == 10 * len(g["node_id"]) * len(seeds) * 8
+        # a batch beyond one 64-seed tile runs tile after tile
+        many = (np.arange(70, dtype=np.int64) * 60 // 70).astype(np.int32)
+        mi, ms, mc = pr.RecommendationBatch(many, 0.15, 4, 5)
+        qi, qs, qc = F.recommend_batch(many, 0.15, 4, 5)
+        ok1 = ok1 and bool((mc == qc).all() and (mi == qi).all() and np.abs(ms - qs).max() <= 1e-9)
         # (2) seed-sharded batch: every rank computes its block (oracle as the stand-in compute), then gathers
         all_seeds = np.arange(0, 60, 3, dtype=np.int32)
         lo, hi = pt.shard_bounds(len(all_seeds), world, rank)
