@@ -2,6 +2,8 @@
 // usable gfx950 device every compute entry fails with RWR_E_NO_DEVICE.
 #include <stdarg.h>
 #include <algorithm>
+#include <mutex>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -62,6 +64,55 @@ struct DeviceGuard {
     }                                                                                                            \
     rwr::DeviceGuard dev_guard__((g)->device);                                                                   \
     if (dev_guard__.rc != RWR_OK) return dev_guard__.rc
+
+// Streams, events and the pinned result buffer of a handle are expensive to create and destroy (several hundred
+// microseconds together) -- more than everything else the library does for an ego-network-sized graph, and the harness
+// creates and drops one Graph per fold and methodology (Experiment.cs:69-105).  They are therefore recycled: a destroyed
+// handle parks its set in a small per-process pool (per device), the next created handle on that device takes it.
+struct HandleKit {
+    int device = -1;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr;
+    void *pin = nullptr;
+};
+static std::mutex g_kit_mutex;
+static std::vector<HandleKit> g_kits;
+constexpr size_t KIT_POOL_MAX = 32;
+
+static bool kit_take(int device, HandleKit *out)
+{
+    std::lock_guard<std::mutex> lk(g_kit_mutex);
+    for (size_t i = 0; i < g_kits.size(); ++i)
+        if (g_kits[i].device == device) {
+            *out = g_kits[i];
+            g_kits.erase(g_kits.begin() + (long)i);
+            return true;
+        }
+    return false;
+}
+static void kit_destroy(HandleKit &k)
+{
+    if (k.ev_fork) (void)hipEventDestroy(k.ev_fork);
+    if (k.ev_join) (void)hipEventDestroy(k.ev_join);
+    if (k.ev_a) (void)hipEventDestroy(k.ev_a);
+    if (k.ev_b) (void)hipEventDestroy(k.ev_b);
+    if (k.stream) (void)hipStreamDestroy(k.stream);
+    if (k.stream2) (void)hipStreamDestroy(k.stream2);
+    if (k.pin) (void)hipHostFree(k.pin);
+    k = HandleKit{};
+}
+static void kit_give(HandleKit &k)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_kit_mutex);
+        if (k.stream && k.stream2 && g_kits.size() < KIT_POOL_MAX) {
+            g_kits.push_back(k);
+            k = HandleKit{};
+            return;
+        }
+    }
+    kit_destroy(k);
+}
 
 }  // namespace rwr
 
@@ -153,15 +204,22 @@ int32_t rwr_graph_create(int32_t n, const int64_t *node_id, const uint8_t *node_
     }
     // the seed-row chain (stream2) is latency-bound and must not queue behind the SpMM's half-million
     // workgroups: give its stream the highest dispatch priority
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithPriority(&g->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreate(&g->ev_a) != hipSuccess || hipEventCreate(&g->ev_b) != hipSuccess) {
-        set_error("stream/event creation failed: %s", hipGetErrorString(hipGetLastError()));
-        return fail(RWR_E_HIP);
+    HandleKit kit;
+    if (kit_take(g->device, &kit)) {   // recycled from a destroyed handle (idle: its streams were synchronised)
+        g->stream = kit.stream; g->stream2 = kit.stream2;
+        g->ev_fork = kit.ev_fork; g->ev_join = kit.ev_join; g->ev_a = kit.ev_a; g->ev_b = kit.ev_b;
+        g->sm_pin = kit.pin;
+    } else {
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithPriority(&g->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreate(&g->ev_a) != hipSuccess || hipEventCreate(&g->ev_b) != hipSuccess) {
+            set_error("stream/event creation failed: %s", hipGetErrorString(hipGetLastError()));
+            return fail(RWR_E_HIP);
+        }
     }
     rc = graph_build(g, node_id, node_type, rowptr, dst, etype, w);
     if (rc != RWR_OK) return fail(rc);
@@ -197,13 +255,12 @@ int32_t rwr_graph_destroy(rwr_graph *g)
     rwr::DeviceGuard dev_guard(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->stream2) (void)hipStreamSynchronize(g->stream2);
-    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
-    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
-    if (g->ev_a) (void)hipEventDestroy(g->ev_a);
-    if (g->ev_b) (void)hipEventDestroy(g->ev_b);
-    if (g->stream) (void)hipStreamDestroy(g->stream);
-    if (g->stream2) (void)hipStreamDestroy(g->stream2);
-    if (g->sm_pin) (void)hipHostFree(g->sm_pin);
+    HandleKit kit;
+    kit.device = g->device;
+    kit.stream = g->stream; kit.stream2 = g->stream2;
+    kit.ev_fork = g->ev_fork; kit.ev_join = g->ev_join; kit.ev_a = g->ev_a; kit.ev_b = g->ev_b;
+    kit.pin = g->sm_pin;
+    kit_give(kit);            // (parked for the next handle on this device, or destroyed when the pool is full)
     delete g;
     return RWR_OK;
 }

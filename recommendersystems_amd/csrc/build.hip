@@ -166,14 +166,15 @@ __global__ __launch_bounds__(256) void k_order_keys(int32_t n, const int64_t *__
                                                     const uint8_t *__restrict__ node_type,
                                                     const int64_t *__restrict__ node_id,
                                                     uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval,
-                                                    int *__restrict__ maxdeg, int order_mode)
+                                                    int *__restrict__ maxdeg, int order_mode, uint32_t top)
 {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t deg = (uint32_t)(in_ptr[i + 1] - in_ptr[i]);
-    // ascending sort of ~deg == in-degree descending; mode 2: by power-of-two degree class only
-    // (stable, so rows keep their natural order inside a class); mode 1: natural order
-    dkey[i] = (order_mode == 1) ? 0u : (order_mode == 2) ? ~(uint32_t)(32 - __clz((int)deg)) : ~deg;
+    // ascending sort of (top - deg) == in-degree descending (top = the link count, an upper bound of every in-degree: the
+    // keys then have only as many bits as the link count, and the radix sort as few passes); mode 2: by power-of-two
+    // degree class only (stable, so rows keep their natural order inside a class); mode 1: natural order
+    dkey[i] = (order_mode == 1) ? 0u : (order_mode == 2) ? (uint32_t)__clz((int)deg) : (top - deg);
     dval[i] = (uint32_t)i;
     atomicMax(maxdeg, (int)deg);
 }
@@ -181,25 +182,27 @@ __global__ __launch_bounds__(256) void k_order_keys(int32_t n, const int64_t *__
 // single-seed SpMV order: phase (ITEM rows first) then in-degree descending
 __global__ __launch_bounds__(256) void k_order_keys_phase(int32_t n, const int64_t *__restrict__ in_ptr,
                                                           const uint8_t *__restrict__ node_type,
-                                                          uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval)
+                                                          uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval,
+                                                          uint32_t top, int top_bits)
 {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t deg = (uint32_t)(in_ptr[i + 1] - in_ptr[i]);
     const uint32_t phase = node_type[i] == RWR_NODE_ITEM ? 0u : 1u;
-    dkey[i] = (phase << 31) | (0x7FFFFFFFu - (deg & 0x7FFFFFFFu));
+    dkey[i] = (phase << top_bits) | (top - deg);
     dval[i] = (uint32_t)i;
 }
 
 // items by id descending: ascending sort of ~orderable(id) over the ITEM rows only (every 64-bit key value is a
 // legitimate id -- INT64_MIN maps to ~0 -- so non-items cannot be parked behind a sentinel key)
+// (keys are taken relative to the largest id, so that they have only as many bits as the id RANGE needs)
 __global__ void k_item_id_keys(int32_t n_items, const int32_t *__restrict__ item_rows, const int64_t *__restrict__ node_id,
-                               uint64_t *__restrict__ ikey, uint32_t *__restrict__ ival)
+                               uint64_t *__restrict__ ikey, uint32_t *__restrict__ ival, uint64_t top)
 {
     int32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_items) return;
     const int32_t i = item_rows[q];
-    ikey[q] = ~i64_orderable(node_id[i]);
+    ikey[q] = top - i64_orderable(node_id[i]);
     ival[q] = (uint32_t)i;
 }
 
@@ -253,8 +256,19 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     }
     g->h_rowptr.assign(rowptr, rowptr + n + 1);
     int32_t n_items = 0;
-    for (int32_t i = 0; i < n; ++i) n_items += (node_type[i] == RWR_NODE_ITEM);
+    uint64_t id_lo = ~0ull, id_hi = 0ull;               // range of the ITEM ids in the order-preserving unsigned form
+    for (int32_t i = 0; i < n; ++i)
+        if (node_type[i] == RWR_NODE_ITEM) {
+            ++n_items;
+            const uint64_t k = i64_orderable(node_id[i]);
+            id_lo = k < id_lo ? k : id_lo;
+            id_hi = k > id_hi ? k : id_hi;
+        }
     g->n_items = n_items;
+    // items by id DESCENDING = ascending (id_hi - key): as many key bits as the id range needs (ids of a loader are
+    // small consecutive numbers: two radix passes instead of eight)
+    g->id_key_top = n_items > 0 ? id_hi : 0;
+    g->id_key_bits = n_items > 0 ? (bit_length(id_hi - id_lo) > 0 ? bit_length(id_hi - id_lo) : 1) : 1;
 
     RWR_TRY(g->node_id.alloc(n));
     RWR_TRY(g->node_type.alloc(n));
@@ -392,14 +406,18 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     RWR_TRY(ikey2.alloc(n));
     RWR_TRY(ival.alloc(n));
     RWR_TRY(ival2.alloc(n));
+    // (every in-degree is <= the number of explicit links: `top - deg` keys need bit_length(nnz) bits, not 32)
+    const uint32_t top = (uint32_t)nnz;
+    const int top_bits = bit_length((uint64_t)nnz) > 0 ? bit_length((uint64_t)nnz) : 1;
     hipLaunchKernelGGL(k_order_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->in_ptr.p, g->node_type.p,
-                       g->node_id.p, skey.p, sval.p, flags.p + 2, order_mode);
+                       g->node_id.p, skey.p, sval.p, flags.p + 2, order_mode, top);
     RWR_HIP(hipGetLastError());
-    RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, 32, temp.p, s, &alt));
+    RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, order_mode == 0 ? top_bits : 8, temp.p, s, &alt));
     hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p, g->row_order.p,
                        (int64_t)n);
-    hipLaunchKernelGGL(k_order_keys_phase, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->in_ptr.p, g->node_type.p, skey.p, sval.p);
-    RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, 32, temp.p, s, &alt));
+    hipLaunchKernelGGL(k_order_keys_phase, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->in_ptr.p, g->node_type.p, skey.p, sval.p,
+                       top, top_bits);
+    RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, top_bits + 1, temp.p, s, &alt));
     hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p, g->row_order_x.p,
                        (int64_t)n);
     if (first) {   // (the node arrays never change: an incremental rebuild keeps both item orders)
@@ -411,8 +429,8 @@ static int32_t graph_derive(rwr_graph *g, bool first)
                                g->item_rows.p, (int64_t)n_items);
         if (n_items > 0) {
             hipLaunchKernelGGL(k_item_id_keys, dim3(cdiv(n_items, 256)), dim3(256), 0, s, n_items, g->item_rows.p,
-                               g->node_id.p, ikey.p, ival.p);
-            RWR_TRY(radix_sort_pairs<uint64_t>(ikey.p, ikey2.p, ival.p, ival2.p, (size_t)n_items, 1, 64, temp.p, s, &alt));
+                               g->node_id.p, ikey.p, ival.p, g->id_key_top);
+            RWR_TRY(radix_sort_pairs<uint64_t>(ikey.p, ikey2.p, ival.p, ival2.p, (size_t)n_items, 1, g->id_key_bits, temp.p, s, &alt));
             hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n_items, 256)), dim3(256), 0, s, alt ? ival2.p : ival.p,
                                g->item_order.p, (int64_t)n_items);
         }

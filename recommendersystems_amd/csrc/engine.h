@@ -10,6 +10,8 @@ struct rwr_graph {
     int64_t nnz_raw = 0;     // links handed over
     int64_t nnz = 0;         // explicit links = entries of the transition matrix
     int32_t n_items = 0;     // nodes of type ITEM
+    uint64_t id_key_top = 0; // largest ITEM id (order-preserving unsigned form) and the bits of the id range: sort keys of item_order
+    int32_t id_key_bits = 64;
     int32_t uniform = 0;     // every row's explicit raw weights equal
     // Value-free matrix path (uniform && nonneg, RWR_VALUE_FREE != 0).  Every out-link of source i then carries the SAME
     // normalised weight w_src[i] (Graph.cs:79-81 divides equal raw weights by one sum), so the product Model.cs:87 adds,
