@@ -71,8 +71,8 @@ struct DeviceGuard {
 // handle parks its set in a small per-process pool (per device), the next created handle on that device takes it.
 struct HandleKit {
     int device = -1;
-    hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_h0 = nullptr, ev_h1 = nullptr;
     void *pin = nullptr;
 };
 static std::mutex g_kit_mutex;
@@ -96,6 +96,9 @@ static void kit_destroy(HandleKit &k)
     if (k.ev_join) (void)hipEventDestroy(k.ev_join);
     if (k.ev_a) (void)hipEventDestroy(k.ev_a);
     if (k.ev_b) (void)hipEventDestroy(k.ev_b);
+    if (k.ev_h0) (void)hipEventDestroy(k.ev_h0);
+    if (k.ev_h1) (void)hipEventDestroy(k.ev_h1);
+    if (k.stream3) (void)hipStreamDestroy(k.stream3);
     if (k.stream) (void)hipStreamDestroy(k.stream);
     if (k.stream2) (void)hipStreamDestroy(k.stream2);
     if (k.pin) (void)hipHostFree(k.pin);
@@ -105,7 +108,7 @@ static void kit_give(HandleKit &k)
 {
     {
         std::lock_guard<std::mutex> lk(g_kit_mutex);
-        if (k.stream && k.stream2 && g_kits.size() < KIT_POOL_MAX) {
+        if (k.stream && k.stream2 && k.stream3 && g_kits.size() < KIT_POOL_MAX) {
             g_kits.push_back(k);
             k = HandleKit{};
             return;
@@ -206,14 +209,18 @@ int32_t rwr_graph_create(int32_t n, const int64_t *node_id, const uint8_t *node_
     // workgroups: give its stream the highest dispatch priority
     HandleKit kit;
     if (kit_take(g->device, &kit)) {   // recycled from a destroyed handle (idle: its streams were synchronised)
-        g->stream = kit.stream; g->stream2 = kit.stream2;
+        g->stream = kit.stream; g->stream2 = kit.stream2; g->stream3 = kit.stream3;
         g->ev_fork = kit.ev_fork; g->ev_join = kit.ev_join; g->ev_a = kit.ev_a; g->ev_b = kit.ev_b;
+        g->ev_h0 = kit.ev_h0; g->ev_h1 = kit.ev_h1;
         g->sm_pin = kit.pin;
     } else {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithPriority(&g->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&g->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev_h0, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev_h1, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess ||
             hipEventCreate(&g->ev_a) != hipSuccess || hipEventCreate(&g->ev_b) != hipSuccess) {
@@ -255,9 +262,11 @@ int32_t rwr_graph_destroy(rwr_graph *g)
     rwr::DeviceGuard dev_guard(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->stream2) (void)hipStreamSynchronize(g->stream2);
+    if (g->stream3) (void)hipStreamSynchronize(g->stream3);
     HandleKit kit;
     kit.device = g->device;
-    kit.stream = g->stream; kit.stream2 = g->stream2;
+    kit.stream = g->stream; kit.stream2 = g->stream2; kit.stream3 = g->stream3;
+    kit.ev_h0 = g->ev_h0; kit.ev_h1 = g->ev_h1;
     kit.ev_fork = g->ev_fork; kit.ev_join = g->ev_join; kit.ev_a = g->ev_a; kit.ev_b = g->ev_b;
     kit.pin = g->sm_pin;
     kit_give(kit);            // (parked for the next handle on this device, or destroyed when the pool is full)

@@ -444,16 +444,20 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     RWR_HIP(hipMemcpy(g->h_in_ptr.data(), g->in_ptr.p, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost));
     g->h_dangling.resize((size_t)n);
     RWR_HIP(hipMemcpy(g->h_dangling.data(), g->dangling.p, (size_t)n, hipMemcpyDeviceToHost));
-    g->bin_end[0] = g->bin_end[1] = g->bin_end[2] = g->bin_huge = 0;
-    for (int ph = 0; ph < 2; ++ph) g->x_rows[ph] = g->x_bins[ph][0] = g->x_bins[ph][1] = g->x_bins[ph][2] = 0;
+    g->bin_end[0] = g->bin_end[1] = g->bin_end[2] = g->bin_huge = g->bin_hub = 0;
+    static const int hub_t_env = [] { const char *e = getenv("RWR_HUB_T"); return e ? atoi(e) : 2048; }();   // (measured best on the MovieLens-shaped graph: 2048 / prefix 256)
+    g->hub_t = hub_t_env < 128 ? 128 : hub_t_env;   // (hub rows are a prefix of the wave-per-row bin: >= 128 in-links)
+    for (int ph = 0; ph < 2; ++ph) g->x_rows[ph] = g->x_hub[ph] = g->x_bins[ph][0] = g->x_bins[ph][1] = g->x_bins[ph][2] = 0;
     for (int32_t i = 0; i < n; ++i) {
         const int64_t deg = g->h_in_ptr[i + 1] - g->h_in_ptr[i];
         g->bin_huge += deg >= 2048;
+        g->bin_hub += deg >= g->hub_t;
         g->bin_end[0] += deg >= 128;
         g->bin_end[1] += deg >= 32;
         g->bin_end[2] += deg >= 4;
         const int ph = g->h_is_item[i] ? 0 : 1;
         g->x_rows[ph] += 1;
+        g->x_hub[ph] += deg >= g->hub_t;
         g->x_bins[ph][0] += deg >= 128;
         g->x_bins[ph][1] += deg >= 32;
         g->x_bins[ph][2] += deg >= 4;

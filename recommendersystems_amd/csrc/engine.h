@@ -27,7 +27,7 @@ struct rwr_graph {
     int32_t poisoned = 0;    // a failed incremental rebuild left raw and derived arrays out of step: every entry point refuses
     // rows of row_order (in-degree descending) with in-degree >= 128 / >= 32 / >= 4: lane-width bins of the K = 1 vector SpMV
     int32_t bin_end[3] = {0, 0, 0};
-    int32_t bin_huge = 0;    // rows with in-degree >= 2048: one 1024-thread workgroup per row
+    int32_t bin_huge = 0;    // rows with in-degree >= 2048: FAST: one 1024-thread workgroup per row; EXACT: k_spmv_exact_hub
     rwr_opts opts{};
 
     // node SoA (struct Node, Graph.cs:4-17)
@@ -57,6 +57,8 @@ struct rwr_graph {
     rwr::DevBuf<int32_t> row_order_x;
     int32_t x_rows[2] = {0, 0};
     int32_t x_bins[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    int32_t x_hub[2] = {0, 0};        // rows of phase p with in-degree >= hub_t (hub rows of the exact single-seed SpMV)
+    int32_t bin_hub = 0, hub_t = 2048; // ... and of the one-phase order; the threshold (RWR_HUB_T)
     std::vector<uint8_t> h_is_item;
     rwr::DevBuf<int32_t> item_order;  // ITEM rows by id descending
     rwr::DevBuf<int32_t> item_rows;   // ITEM rows by row index ascending
@@ -102,6 +104,8 @@ struct rwr_graph {
     std::vector<int32_t> part_seeds;
 
     hipStream_t stream = nullptr, stream2 = nullptr;
+    hipStream_t stream3 = nullptr;    // hub rows of the exact single-seed SpMV, beside the binned kernel
+    hipEvent_t ev_h0 = nullptr, ev_h1 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;   // profiling pairs
 
@@ -144,9 +148,11 @@ int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double
 int32_t model_deliver(rwr_graph *g, int32_t seed, double d, const double *rank_in, double *next_out);
 // spmv.hip: single-seed SpMV (EXACT: list-order sums, rows binned by in-degree; FAST: vector-CSR with tree reductions)
 // (zin != nullptr: value-free form -- gathers zin, reads no per-entry value; zout (may be nullptr) receives the next z)
+// (hub_scan: every addend is known to be >= 0 and finite -- weights, ranks and 1-d -- so that rows of >= 2048 in-links may
+//  be summed by the exact parallel reduction of pf.h instead of one add at a time)
 void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *seeds, double c1, int skip,
                        const uint32_t *act, uint32_t *nz_out, hipStream_t s, const double *zin = nullptr,
-                       double *zout = nullptr);
+                       double *zout = nullptr, bool hub_scan = false);
 void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hipStream_t s, const double *zin = nullptr,
                         double *zout = nullptr);
 // spmv_blocked.hip: single-seed SpMV of dense value-free graphs, z staged through LDS block by block (bitwise the same sums)

@@ -750,7 +750,8 @@ __global__ __launch_bounds__(256) void k_make_z(int64_t elems, int G, const doub
 template <int G>
 static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const int32_t *seeds, double c1,
                         int skip, const uint32_t *nz_in, uint32_t *nz_out, hipStream_t s,
-                        const uint32_t *act = nullptr, const double *Zin = nullptr, double *Zout = nullptr)
+                        const uint32_t *act = nullptr, const double *Zin = nullptr, double *Zout = nullptr,
+                        bool hub_scan = false)
 {
     // Zin != nullptr: value-free form -- the kernels gather Zin (z of the current ranks) instead of X and read no weights
     const bool vf = Zin != nullptr;
@@ -769,7 +770,7 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
             return;
         }
         if (tg == 1 && variant != 0) {
-            launch_spmv_exact(g, X, Y, seeds, c1, skip, act, nz_out, s, Zin, Zout);
+            launch_spmv_exact(g, X, Y, seeds, c1, skip, act, nz_out, s, Zin, Zout, hub_scan);
             return;
         }
     }
@@ -939,6 +940,7 @@ struct GroupIter {
     int chain_kind = 1;  // 0 simple one-lane loop, 1 auto, 2 scan, 3 role-specialised fold
     int act_iters = 0;   // iterations whose SpMM only visits the out-neighbours of non-zero rows
     int64_t dense_steps = 0;   // steps whose SpMM walked every row (no frontier bitmap)
+    bool addends_nonneg = false;   // weights, ranks and 1-d all >= 0 and finite: exact parallel reductions are allowed
 
     GroupIter(rwr_graph *g_, int G_, int tg_, const int32_t *seeds, const int64_t *evoff, double d)
         : g(g_), G(G_), tg(tg_), d_seeds(seeds), d_evoff(evoff), c1(1 - d) /* Model.cs:84: (1 - dampingFactor) */,
@@ -990,6 +992,7 @@ struct GroupIter {
         const int sel = g->opts.seed_row_kernel;
         chain_kind = sel == 1 ? 3 : sel == 2 ? 2 : sel == 3 ? 0 : chain_env;
         const double per_seed = 0.89 * (double)g->nnz / (double)(g->n > 0 ? g->n : 1) + 6.7;
+        addends_nonneg = c1 >= 0.0 && c1 <= 1.0 && g->nonneg && ranks_nonneg;
         scan = g->opts.mode != RWR_MODE_FAST && c1 >= 0.0 && c1 <= 1.0 && g->nonneg && ranks_nonneg &&
                (chain_kind == 2 || (chain_kind == 1 && (double)tg * G * per_seed < scan_work));
         if (scan) RWR_TRY(chain_scan_prepare(g, G, tg, d_seeds, s));
@@ -1056,7 +1059,7 @@ struct GroupIter {
         hipEvent_t a = nullptr, b = nullptr;
         if (prof) { a = pool.get(); b = pool.get(); RWR_HIP(hipEventRecord(a, s)); }
         double *zout = (Zc && !last) ? Zn : nullptr;
-        RWR_DISPATCH_G(G, launch_spmm<GG>(g, tg, X, Y, d_seeds, c1, exact ? 1 : 0, nz_in, nz_out, s, act, Zc, zout));
+        RWR_DISPATCH_G(G, launch_spmm<GG>(g, tg, X, Y, d_seeds, c1, exact ? 1 : 0, nz_in, nz_out, s, act, Zc, zout, addends_nonneg));
         if (prof) { RWR_HIP(hipEventRecord(b, s)); spmm_ev.push_back(a); spmm_ev.push_back(b); g->spmm_ev_dense.push_back(nz_in ? 0 : 1); }
         if (!nz_in) { g->stats.spmm_dense_launches += 1; ++dense_steps; }
         if (exact) {

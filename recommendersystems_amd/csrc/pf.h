@@ -50,4 +50,59 @@ __device__ __forceinline__ double pf_from_m(int eb, long long M)
     return __longlong_as_double((long long)(((unsigned long long)eb << 52) | ((unsigned long long)M - CS_HID)));
 }
 
+// s + v[0] + v[1] + ... strictly in order for ONE WAVE holding 64 * R addends >= 0 in registers -- lane l owns the run
+// [l * R, (l + 1) * R) of the sequence -- as an exact parallel reduction: inside the current binade every run is a
+// parity function, one wave scan composes the 64 runs; the run in which the sum leaves the binade is added with real fp64
+// adds and the lanes behind it start over under the new binade (the shape of cs_redo_block, chain_scan.hip).  While s is
+// zero or subnormal the first run holding a non-zero addend is added with real adds the same way.  Returns the new sum
+// (wave-uniform), bit for bit the sequential one.
+template <int R>
+__device__ __forceinline__ double wave_fold_exact(double s, const double (&v)[R], int lane)
+{
+    bool nzl = false;
+#pragma unroll
+    for (int u = 0; u < R; ++u) nzl = nzl || v[u] != 0.0;
+    int start = 0;
+    while (start < WAVE) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(s);
+        const int eb = (int)((b >> 52) & 0x7ff);
+        int L;
+        if (eb == 0 || eb == 0x7ff) {
+            const unsigned long long nzm = __ballot(lane >= start && nzl);
+            if (!nzm) break;
+            L = __builtin_ctzll(nzm);
+        } else {
+            PF f{0, 0};
+            if (lane >= start && nzl) {
+#pragma unroll
+                for (int u = 0; u < R; ++u) f = pf_compose(f, pf_of(v[u], eb));
+            }
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                PF o;
+                o.d0 = __shfl_up(f.d0, off, WAVE);
+                o.d1 = __shfl_up(f.d1, off, WAVE);
+                if (lane >= off) f = pf_compose(o, f);
+            }
+            const long long m = (long long)((b & CS_FRAC) | CS_HID);
+            const long long Mv = m + ((m & 1) ? f.d1 : f.d0);
+            const unsigned long long cross = __ballot(Mv >= CS_BIG);
+            if (!cross) {
+                s = pf_from_m(eb, __shfl(Mv, WAVE - 1, WAVE));
+                break;
+            }
+            L = __builtin_ctzll(cross);
+            if (L > 0) s = pf_from_m(eb, __shfl(Mv, L - 1, WAVE));
+        }
+        double t = s;
+        if (lane == L) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) t += v[u];
+        }
+        s = __shfl(t, L, WAVE);
+        start = L + 1;
+    }
+    return s;
+}
+
 }  // namespace rwr

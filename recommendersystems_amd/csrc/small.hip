@@ -59,61 +59,16 @@ __device__ double sm_fold_seq(double s, const double *M, int base, int cnt, int 
     return s;
 }
 
-// the same sum for one pass of SM_PASS addends as an exact parallel reduction (the shape of cs_redo_block, chain_scan.hip):
-// lane l owns the run [l * R, (l + 1) * R); inside the current binade every run is a parity function, one wave scan
-// composes them; the run in which the sum leaves the binade is added with real fp64 adds and the lanes behind it start
-// over under the new binade.
+// the same sum for one pass of SM_PASS addends as an exact parallel reduction (pf.h: wave_fold_exact)
 __device__ double sm_fold_scan(double s, const double *M, int base, int cnt, int lane)
 {
     double v[SM_R];
-    bool nzl = false;
 #pragma unroll
     for (int u = 0; u < SM_R; ++u) {
         const int q = lane * SM_R + u;
         v[u] = q < cnt ? M[sm_pad(base + q)] : 0.0;
-        nzl = nzl || v[u] != 0.0;
     }
-    int start = 0;
-    while (start < WAVE) {
-        const unsigned long long b = (unsigned long long)__double_as_longlong(s);
-        const int eb = (int)((b >> 52) & 0x7ff);
-        int L;
-        if (eb == 0 || eb == 0x7ff) {
-            const unsigned long long nzm = __ballot(lane >= start && nzl);
-            if (!nzm) break;
-            L = __builtin_ctzll(nzm);
-        } else {
-            PF f{0, 0};
-            if (lane >= start && nzl) {
-#pragma unroll
-                for (int u = 0; u < SM_R; ++u) f = pf_compose(f, pf_of(v[u], eb));
-            }
-#pragma unroll
-            for (int off = 1; off < WAVE; off <<= 1) {
-                PF o;
-                o.d0 = __shfl_up(f.d0, off, WAVE);
-                o.d1 = __shfl_up(f.d1, off, WAVE);
-                if (lane >= off) f = pf_compose(o, f);
-            }
-            const long long m = (long long)((b & CS_FRAC) | CS_HID);
-            const long long Mv = m + ((m & 1) ? f.d1 : f.d0);
-            const unsigned long long cross = __ballot(Mv >= CS_BIG);
-            if (!cross) {
-                s = pf_from_m(eb, __shfl(Mv, WAVE - 1, WAVE));
-                break;
-            }
-            L = __builtin_ctzll(cross);
-            if (L > 0) s = pf_from_m(eb, __shfl(Mv, L - 1, WAVE));
-        }
-        double t = s;
-        if (lane == L) {
-#pragma unroll
-            for (int u = 0; u < SM_R; ++u) t += v[u];
-        }
-        s = __shfl(t, L, WAVE);
-        start = L + 1;
-    }
-    return s;
+    return wave_fold_exact<SM_R>(s, v, lane);
 }
 
 __global__ __launch_bounds__(SM_THREADS) void k_small_rwr(

@@ -3,6 +3,7 @@
 //          are served cooperatively (parallel loads / gathers / products, sequential adds);
 //   FAST : the classic vector-CSR form with shuffle-butterfly reductions (scores within 1e-6).
 #include "engine.h"
+#include "pf.h"
 
 #include <cstdlib>
 
@@ -238,6 +239,90 @@ __global__ __launch_bounds__(256) void k_spmv_exact_binned(int nb0, int nb1, int
     spmv_exact_lane<VF>(b, nb3, b2, n, in_ptr, in_src, in_w, row_order, x, y, my_seed, c1, act, nz_out, w_src, zout);
 }
 
+// K = 1, EXACT mode, HUB rows (in-degree >= hub_t, 2048 by default: the most liked items of a dense graph, the ego of an ego network).
+// A strictly sequential fp64 sum of L addends takes L dependent adds -- 29 000 of them for the top item of the
+// MovieLens-shaped configuration, ~200 us at the ~16 cycles per entry of the wave body above: the whole SpMV waited for
+// that one row.  When every addend is known to be >= 0 (weights, ranks, 1-d: `hub_scan`), the chain is an INTEGER sum
+// inside each binade of the running sum (pf.h; chain_scan.hip explains the arithmetic), so it reduces in parallel and is
+// still bit for bit the sequential result: the first few hundred entries are added one by one as above (the sum crosses a binade
+// every few entries while it is small), the rest in passes of 1024 -- lane l fetches ITS 16 consecutive entries (64
+// contiguous bytes of indices), gathers their values, and wave_fold_exact composes the 64 runs.  One wave per row; the
+// kernel runs beside k_spmv_exact_binned on a stream of its own.
+constexpr int HS_R = 16;
+constexpr int HS_PASS = WAVE * HS_R;
+template <bool VF>
+__global__ __launch_bounds__(WAVE) void k_spmv_exact_hub(int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
+                                                         const int32_t *__restrict__ in_src,
+                                                         const double *__restrict__ in_w,
+                                                         const int32_t *__restrict__ row_order,
+                                                         const double *__restrict__ x, double *__restrict__ y,
+                                                         const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
+                                                         const double *__restrict__ w_src, double *__restrict__ zout, int prefix)
+{
+    __shared__ double pb[2][WAVE];
+    const int lane = threadIdx.x;
+    const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
+    uint32_t *nz_out = nullptr;
+    for (int32_t r = r0 + blockIdx.x; r < r1; r += gridDim.x) {
+        const int32_t j = row_order[r];
+        if (j == my_seed) continue;
+        int64_t p = in_ptr[j];
+        const int64_t e = in_ptr[j + 1];
+        double acc = 0.0;
+        {   // the first `prefix` entries one by one (the shape of spmv_exact_wave)
+            const int64_t ea = (e - p) < prefix ? e : p + prefix;
+            int buf = 0;
+            double cur = 0.0;
+            if (p + lane < ea) {
+                if (VF) cur = x[in_src[p + lane]];
+                else { const double rw = c1 * x[in_src[p + lane]]; cur = rw * in_w[p + lane]; }
+            }
+            while (p < ea) {
+                const int64_t pn = p + WAVE;
+                double nxt = 0.0;
+                if (pn + lane < ea) {
+                    if (VF) nxt = x[in_src[pn + lane]];
+                    else { const double rw = c1 * x[in_src[pn + lane]]; nxt = rw * in_w[pn + lane]; }
+                }
+                pb[buf][lane] = cur;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (ea - p >= WAVE) {
+#pragma unroll
+                    for (int t = 0; t < WAVE; ++t) acc += pb[buf][t];
+                } else {
+                    const int cnt = (int)(ea - p);
+                    for (int t = 0; t < cnt; ++t) acc += pb[buf][t];
+                }
+                buf ^= 1;
+                cur = nxt;
+                p = pn;
+            }
+            p = ea;
+        }
+        // the rest in passes of HS_PASS: every lane's 16 consecutive entries, then the exact parallel fold
+        for (; p < e; p += HS_PASS) {
+            const int64_t left = e - p;
+            const int cnt = left < HS_PASS ? (int)left : HS_PASS;
+            const int64_t q0 = p + (int64_t)lane * HS_R;
+            int32_t idx[HS_R];
+            double v[HS_R];
+#pragma unroll
+            for (int u = 0; u < HS_R; ++u) idx[u] = (lane * HS_R + u < cnt) ? in_src[q0 + u] : -1;
+#pragma unroll
+            for (int u = 0; u < HS_R; ++u) {
+                v[u] = 0.0;
+                if (idx[u] >= 0) {
+                    if (VF) v[u] = x[idx[u]];
+                    else { const double rw = c1 * x[idx[u]]; v[u] = rw * in_w[q0 + u]; }      // Model.cs:84,87
+                }
+            }
+            acc = wave_fold_exact<HS_R>(acc, v, lane);                                        // list order, bit for bit
+        }
+        if (lane == 0) RWR_SPMV_STORE(j, acc)
+    }
+}
+
 // K = 1, FAST mode: the classic vector-CSR SpMV.  W lanes share one destination row: each lane streams every W-th
 // entry of the row's in-list (coalesced index and weight reads), gathers x, keeps a private partial sum, and the W
 // partials are combined with a shuffle butterfly whose shape depends only on W -- rows of equal structure get
@@ -368,7 +453,7 @@ void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hip
 // (RWR_GROUP_ROWS = 0 keeps everything under 128 on the lane-per-row form; RWR_ROW_ORDER != 0 or RWR_SPMV_PHASES = 0: one
 // pass in row_order).  One launch per phase.
 void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *seeds, double c1, int skip,
-                       const uint32_t *act, uint32_t *nz_out, hipStream_t s, const double *zin, double *zout)
+                       const uint32_t *act, uint32_t *nz_out, hipStream_t s, const double *zin, double *zout, bool hub_scan)
 {
     static const bool by_degree = [] { const char *e = getenv("RWR_ROW_ORDER"); return !e || atoi(e) == 0; }();
     static const int group_rows = [] { const char *e = getenv("RWR_GROUP_ROWS"); return e ? atoi(e) : 2; }();
@@ -382,9 +467,36 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
         return;
     }
     const double *gs = vf ? zin : X;       // gather source
+    // hub rows (>= hub_t in-links, first in the in-degree order): exact parallel reduction, one wave per row, on a stream of
+    // its own beside the binned kernel (dense steps only, and only when every addend is known to be >= 0)
+    static const int hub_env = [] { const char *e = getenv("RWR_HUB_SCAN"); return e ? atoi(e) : 1; }();
+    const bool hubs = hub_scan && hub_env && by_degree && !act && !nz_out && g->stream3 && s != g->stream3;
+    bool forked = false;
+    auto launch_hubs = [&](const int32_t *order, int32_t ra, int32_t nh) {
+        if (nh <= 0) return;
+        if (!forked) {
+            (void)hipEventRecord(g->ev_h0, s);
+            (void)hipStreamWaitEvent(g->stream3, g->ev_h0, 0);
+            forked = true;
+        }
+        const unsigned grid = (unsigned)(nh < 4096 ? nh : 4096);
+        static const int prefix = [] { const char *e = getenv("RWR_HUB_PREFIX"); return e ? atoi(e) : 256; }();
+        if (vf)
+            hipLaunchKernelGGL(k_spmv_exact_hub<true>, dim3(grid), dim3(WAVE), 0, g->stream3, ra, ra + nh, g->in_ptr.p, g->in_src.p,
+                               g->in_w.p, order, gs, Y, seeds, c1, skip, g->w_src.p, zout, prefix);
+        else
+            hipLaunchKernelGGL(k_spmv_exact_hub<false>, dim3(grid), dim3(WAVE), 0, g->stream3, ra, ra + nh, g->in_ptr.p, g->in_src.p,
+                               g->in_w.p, order, gs, Y, seeds, c1, skip, g->w_src.p, zout, prefix);
+    };
     auto blocks_for = [](int64_t rows, int W) { const int64_t b = (rows * W + 255) / 256; return (int)(b < 0 ? 0 : (b > 16384 ? 16384 : b)); };
-    auto launch = [&](const int32_t *order, int32_t ra, int32_t rows, const int32_t bins[3]) {
+    auto launch = [&](const int32_t *order, int32_t ra0, int32_t rows, const int32_t bins[3], int32_t nh) {
         if (rows <= 0) return;
+        if (!hubs) nh = 0;
+        launch_hubs(order, ra0, nh);
+        const int32_t ra = ra0 + nh;                    // the binned kernel starts behind the hub rows
+        rows -= nh;
+        int32_t bins_adj[3] = {bins[0] - nh, bins[1] - nh, bins[2] - nh};
+        bins = bins_adj;
         const int32_t b0 = ra + (by_degree ? bins[0] : 0);
         const int32_t b1 = (by_degree && group_rows >= 1) ? ra + bins[1] : b0;
         const int32_t b2 = (by_degree && group_rows >= 2) ? ra + bins[2] : b1;
@@ -399,10 +511,14 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
                                b1, b2, rend, g->in_ptr.p, g->in_src.p, g->in_w.p, order, gs, Y, seeds, c1, skip, act, nz_out, g->w_src.p, zout);
     };
     if (by_degree && phases) {
-        launch(g->row_order_x.p, 0, g->x_rows[0], g->x_bins[0]);
-        launch(g->row_order_x.p, g->x_rows[0], g->x_rows[1], g->x_bins[1]);
+        launch(g->row_order_x.p, 0, g->x_rows[0], g->x_bins[0], g->x_hub[0]);
+        launch(g->row_order_x.p, g->x_rows[0], g->x_rows[1], g->x_bins[1], g->x_hub[1]);
     } else {
-        launch(g->row_order.p, 0, g->n, g->bin_end);
+        launch(g->row_order.p, 0, g->n, g->bin_end, g->bin_hub);
+    }
+    if (forked) {                                       // the step is complete when both kernels are
+        (void)hipEventRecord(g->ev_h1, g->stream3);
+        (void)hipStreamWaitEvent(s, g->ev_h1, 0);
     }
 }
 

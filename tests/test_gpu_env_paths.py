@@ -34,6 +34,7 @@ def run_child(env_extra):
     {"RWR_BIG_N": "100", "RWR_SPMV_PHASES": "1", "RWR_ACT_ITERS": "3"},
     {"RWR_BIG_N": "100", "RWR_VALUE_FREE": "0"},
     {"RWR_SPMV_BLOCKED": "1"},
+    {"RWR_HUB_SCAN": "0"},
     {"RWR_SMALL": "0"},
     {"RWR_SMALL": "0", "RWR_VALUE_FREE": "0"},
     {"RWR_SPMM": "0"},
