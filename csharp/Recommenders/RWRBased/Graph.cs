@@ -8,7 +8,11 @@ namespace Recommenders.RWRBased {
     public class Graph {
         public Dictionary<int, Node> nodes;
         public Dictionary<int, List<ForwardLink>> edges;
-        Dictionary<int, ForwardLink[]> normalized;        // materialised lazily from the device
+        // PUBLIC FIELD as in the reference (Graph.cs:43).  buildGraph() fills it from the device for graphs of up to
+        // GraphFieldLimit raw links (every ego network of the harness); beyond that it stays null -- a field cannot be
+        // materialised lazily -- and LoadNormalizedGraph() fills it on request.  The harness never reads it.
+        public Dictionary<int, ForwardLink[]> graph;
+        public static long GraphFieldLimit = 5000000;
         internal GraphHandle handle;
         long[] rowptr; int[] dst; byte[] etype;
         long[] sentId; byte[] sentType; double[] sentW;   // what the device currently holds (for incremental rebuilds)
@@ -34,7 +38,7 @@ namespace Recommenders.RWRBased {
                 if (!edges.ContainsKey(i)) continue;
                 foreach (ForwardLink l in edges[i]) { dst[e] = l.targetNode; etype[e] = (byte)l.type; w[e] = l.weight; e++; }
             }
-            normalized = null;
+            graph = null;
             // buildGraph() called again on the same object after the host mutated link types or weights in place
             // (Experiment.cs:84-101 relabels FRIENDSHIP -> UNDEFINED): same nodes, same list lengths, same targets
             // => send only the links that differ (rwr_graph_update_links); the device state is identical either way.
@@ -46,10 +50,11 @@ namespace Recommenders.RWRBased {
                     }
                 Native.Check(Native.rwr_graph_update_links(handle, idx.Count, idx.ToArray(), nt.ToArray(), nw.ToArray()));
             } else {
-                var opts = new RwrOpts { struct_size = 32, device = -1, mode = -1 };
+                var opts = new RwrOpts { struct_size = 40, device = -1, mode = -1 };
                 Native.Check(Native.rwr_graph_create(n, id, type, rowptr, dst, etype, w, ref opts, out handle));
             }
             sentId = id; sentType = type; sentW = w;
+            if (m <= GraphFieldLimit) LoadNormalizedGraph();
         }
 
         bool SameTopology(long[] id, byte[] type, long[] oldRowptr, int[] oldDst) {
@@ -60,24 +65,21 @@ namespace Recommenders.RWRBased {
             return true;
         }
 
-        // public field of the reference (Graph.cs:43), served as a property backed by the device copy
-        public Dictionary<int, ForwardLink[]> graph {
-            get {
-                if (normalized == null) {
-                    int n = nodes.Count;
-                    var wn = new double[System.Math.Max(1, dst.Length)]; var dg = new byte[n];
-                    Native.Check(Native.rwr_graph_get_normalized(handle, wn, dg));
-                    normalized = new Dictionary<int, ForwardLink[]>();
-                    for (int i = 0; i < n; i++) {
-                        if (dg[i] != 0) { normalized.Add(i, null); continue; }
-                        var list = new List<ForwardLink>();
-                        for (long p = rowptr[i]; p < rowptr[i + 1]; p++)
-                            if (etype[p] != 0) list.Add(new ForwardLink(dst[p], (EdgeType)etype[p], wn[p]));
-                        normalized.Add(i, list.ToArray());
-                    }
-                }
-                return normalized;
+        // fills the public field `graph` (Graph.cs:43) from the device: normalised explicit links per node, null for
+        // dangling nodes (Graph.cs:53,64,86)
+        public void LoadNormalizedGraph() {
+            int n = nodes.Count;
+            var wn = new double[System.Math.Max(1, dst.Length)]; var dg = new byte[n];
+            Native.Check(Native.rwr_graph_get_normalized(handle, wn, dg));
+            var normalized = new Dictionary<int, ForwardLink[]>();
+            for (int i = 0; i < n; i++) {
+                if (dg[i] != 0) { normalized.Add(i, null); continue; }
+                var list = new List<ForwardLink>();
+                for (long p = rowptr[i]; p < rowptr[i + 1]; p++)
+                    if (etype[p] != 0) list.Add(new ForwardLink(dst[p], (EdgeType)etype[p], wn[p]));
+                normalized.Add(i, list.ToArray());
             }
+            graph = normalized;
         }
 
         public int size() { return nodes.Count; }

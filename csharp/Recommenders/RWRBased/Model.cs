@@ -34,6 +34,7 @@ namespace Recommenders.RWRBased {
         }
 
         void Run(int mode, double value) {
+            CheckRestart();
             if (CtorState()) {
                 long iters;
                 Native.Check(Native.rwr_model_run(graph.handle, seed, dampingFactor, mode, value, rank, out iters));
@@ -56,8 +57,19 @@ namespace Recommenders.RWRBased {
         public void run(double threshold) { Run(1, threshold); }
         public void run(int nIterations) { Run(0, nIterations); }
 
+        // `restart` is a public field of the reference, but only the constructors' restart vectors have a device kernel
+        // (one-hot at the seed / uniform 1/n): a host-edited vector is refused, as the Python mirror does
+        void CheckRestart() {
+            for (int i = 0; i < nNodes; i++) {
+                double expect = seed < 0 ? 1d / nNodes : (i == seed ? 1d : 0d);
+                if (restart[i] != expect)
+                    throw new System.NotSupportedException("Model.restart was modified: only the constructors' restart vectors are supported");
+            }
+        }
+
         // the reference's public single steps (Model.cs:76,103,110)
         public void deliverRanks() {
+            CheckRestart();
             for (int i = 0; i < nNodes; i++)
                 if (nextRank[i] != 0)
                     throw new System.InvalidOperationException("deliverRanks() on a non-zero nextRank: call updateRanks() first");

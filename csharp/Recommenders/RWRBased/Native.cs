@@ -9,6 +9,7 @@ namespace Recommenders.RWRBased {
     internal struct RwrOpts {
         public int struct_size, device, mode, tile_seeds, tile_group, profile;
         public long workspace_bytes;
+        public int seed_row_kernel, reserved0;
     }
 
     internal sealed class GraphHandle : SafeHandle {

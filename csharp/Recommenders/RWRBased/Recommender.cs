@@ -27,6 +27,7 @@ namespace Recommenders.RWRBased {
 
         // addition: many seeds in one call (results identical to calling Recommendation per seed)
         public List<KeyValuePair<long, double>>[] RecommendationBatch(int[] seeds, float dampingFactor, int nIteration, int topN) {
+            if (topN < 1) throw new System.ArgumentOutOfRangeException("topN", "RecommendationBatch needs topN >= 1 (rwr_recommend_batch)");
             int K = seeds.Length;
             var ids = new long[(long)K * topN]; var scores = new double[(long)K * topN]; var counts = new int[K];
             Native.Check(Native.rwr_recommend_batch(graph.handle, seeds, K, dampingFactor, nIteration, topN, ids, scores, counts));

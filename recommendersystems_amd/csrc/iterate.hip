@@ -300,6 +300,55 @@ __global__ __launch_bounds__(256) void k_spmm_vf_wide(int32_t n, const int64_t *
     }
 }
 
+// TIMING-ONLY probe (RWR_SPMM_SLICE_PROBE, results are WRONG): the gather pattern of a source-sliced SpMM in which XCD x
+// only ever touches the rank-matrix rows of source slice x, so that the eight 4 MiB L2s cache eight different hot sets
+// instead of the same one.  Workgroup 8*rb + x (workgroups b and b + 8 share an XCD) walks the rows of row block rb and
+// gathers only the entries whose source lies in slice x; every row is thus visited by eight workgroups and the launch
+// performs exactly the gathers of the real kernel.  What a correct version would add on top -- the running sums handed
+// from slice to slice through Y in slice order -- is NOT here: this measures the best the scheme could do.
+struct SliceBounds { int32_t b[9]; };
+template <int G, int CH>
+__global__ __launch_bounds__(256) void k_spmm_slice_probe(int32_t n, const int64_t *__restrict__ in_ptr,
+                                                          const int32_t *__restrict__ in_src,
+                                                          const int32_t *__restrict__ row_order,
+                                                          const double *__restrict__ Z, double *__restrict__ Y, SliceBounds sb)
+{
+    constexpr int RPW = WAVE / G;
+    const int tile = blockIdx.y;
+    const size_t toff = (size_t)tile * (size_t)n * G;
+    Z += toff;
+    Y += toff;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int sub = lane / G, k = lane % G;
+    const int gbase = (lane - k) << 2;
+    const int x = blockIdx.x & 7;
+    const int32_t lo = sb.b[x], hi = sb.b[x + 1];
+    const int wpb = blockDim.x / WAVE;
+    const int64_t nwaves = (int64_t)(gridDim.x / 8) * wpb;
+    for (int64_t rb = ((int64_t)(blockIdx.x / 8) * wpb + threadIdx.x / WAVE) * RPW; rb < n; rb += nwaves * RPW) {
+        const int64_t r = rb + sub;
+        int32_t j = -1;
+        int64_t p = 0, e = 0;
+        if (r < n) { j = row_order[r]; p = in_ptr[j]; e = in_ptr[j + 1]; }
+        double acc = 0.0;
+        while (__any(p < e)) {
+            const int64_t left = e - p;
+            const int cnt = left > CH ? CH : (left > 0 ? (int)left : 0);
+            const int32_t my_idx = (k < cnt) ? in_src[p + k] : 0;
+            double xv[CH];
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int idx = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), my_idx);
+                xv[t] = (t < cnt && idx >= lo && idx < hi) ? Z[(size_t)idx * G + k] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < CH; ++t) acc += xv[t];
+            p += cnt;
+        }
+        if (j >= 0 && x == 0) Y[(size_t)j * G + k] = acc;
+    }
+}
+
 // First iterations: destination rows that can become non-zero = out-neighbours (explicit links) of the rows of X
 // that hold a non-zero.  One thread per bitmap word of the tile; pushes over the RAW out-links.
 __global__ __launch_bounds__(256) void k_mark_active(int32_t n, const uint32_t *__restrict__ nz, uint32_t *__restrict__ act,
@@ -786,6 +835,27 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
         }
     }
     if constexpr (G >= 8) {
+        static const int probe = [] { const char *e = getenv("RWR_SPMM_SLICE_PROBE"); return e ? atoi(e) : 0; }();
+        if (probe && vf && !nz_in && !nz_out && !act) {   // timing-only experiment (see k_spmm_slice_probe): WRONG results
+            SliceBounds sb;
+            if (probe == 1) {
+                for (int q = 0; q <= 8; ++q) sb.b[q] = (int32_t)(((int64_t)g->n * q) / 8);
+            } else {   // equal gather mass per slice: a node is gathered once per out-link
+                const int64_t tot = g->h_rowptr[g->n];
+                int32_t i = 0;
+                sb.b[0] = 0;
+                for (int q = 1; q < 8; ++q) {
+                    while (i < g->n && g->h_rowptr[i] < tot * q / 8) ++i;
+                    sb.b[q] = i;
+                }
+                sb.b[8] = g->n;
+            }
+            constexpr int CHP = (G > 16 ? 16 : G);
+            const unsigned gxp = (gx & ~7u) ? (gx & ~7u) : 8u;
+            hipLaunchKernelGGL((k_spmm_slice_probe<G, CHP>), dim3(gxp, tg), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p,
+                               g->row_order.p, GS, Y, sb);
+            return;
+        }
         if (variant != 0) {
 #define RWR_SPMM_LAUNCH3(CH, CHK, WR, VFF)                                                                         \
     hipLaunchKernelGGL((k_spmm_chunked<G, CH, CHK, WR, VFF>), dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p,    \

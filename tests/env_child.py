@@ -81,13 +81,14 @@ def main():
                 else:
                     assert np.abs(np.asarray(got_sc) - np.asarray(ref_sc)).max(initial=0.0) <= 1e-6, (name, mode, what)
 
-            for seed in (0, 7, n_users - 1):
-                for T in (0, 1, 2, 4, 10):
+            big = len(g["node_id"]) > 10000            # (the larger graphs: fewer single-seed cases, same code paths)
+            for seed in ((0, n_users - 1) if big else (0, 7, n_users - 1)):
+                for T in ((0, 2, 10) if big else (0, 1, 2, 4, 10)):
                     got = rec.Recommendation(seed, 0.15, T)
                     ri, rs = F.recommend(seed, 0.15, T)
                     check([r[0] for r in got], [r[1] for r in got], ri, rs, f"single seed {seed} T {T}")
                     cases += 1
-            for K in (3, 40, 130):
+            for K in ((3, 130) if big else (3, 40, 130)):
                 seeds = (np.arange(K, dtype=np.int64) * n_users // K).astype(np.int32)
                 bi, bs, bc = rec.RecommendationBatch(seeds, 0.15, 10, 20)
                 oi, os_, oc = F.recommend_batch(seeds, 0.15, 10, 20)

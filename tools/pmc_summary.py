@@ -38,6 +38,8 @@ def main():
         for cname, per in counters.items():
             e[f"{cname}_per_launch"] = sum(per.values()) / len(per)
             e[f"launches_in_pass_{cname}"] = len(per)
+        if e.get("TCC_REQ_sum_per_launch"):
+            e["l2_hit_rate"] = e.get("TCC_HIT_sum_per_launch", 0.0) / e["TCC_REQ_sum_per_launch"]
         if "FETCH_SIZE_per_launch" in e:
             e["hbm_side_bytes_per_launch_corrected"] = (2.0 * e["FETCH_SIZE_per_launch"] + e.get("WRITE_SIZE_per_launch", 0.0)) * 1024.0
         kernels[k] = e
@@ -46,14 +48,19 @@ def main():
                              "Infinity-Cache hits are included in FETCH_SIZE",
                "kernels": kernels}
     json.dump(summary, open(out_summary, "w"), indent=1)
-    spmm = {k: v for k, v in kernels.items() if k.startswith("rwr::k_spmm_chunked") and "hbm_side_bytes_per_launch_corrected" in v}
+    # the DENSE variant only (template arguments CHECK = false, WRITE = false): the launches bench.py prices
+    spmm = {k: v for k, v in kernels.items() if k.startswith("rwr::k_spmm_chunked") and ", false, false," in k
+            and "hbm_side_bytes_per_launch_corrected" in v}
     launches = sum(v["launches_in_pass_FETCH_SIZE"] for v in spmm.values())
     if launches:
         total = sum(v["hbm_side_bytes_per_launch_corrected"] * v["launches_in_pass_FETCH_SIZE"] for v in spmm.values())
         m = re.search(r"tile width (\d+)", tag)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
         json.dump({"config": tag.split()[0], "mode": "exact" if "exact" in tag else "fast",
                    "tile_seeds": int(m.group(1)) if m else 0,
-                   "kernel": "k_spmm_chunked (all frontier variants, launch-weighted)", "launches": launches,
+                   "csrc_sha": bench.kernel_source_sha(),
+                   "kernel": "k_spmm_chunked, dense launches (no frontier skipping)", "launches": launches,
                    "bytes_per_launch": total / launches,
                    "source": f"{os.path.basename(out_summary)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 per "
                              "profiles/r01_calibration_fetch_size.json; includes Infinity-Cache hits)"},

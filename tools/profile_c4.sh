@@ -4,7 +4,7 @@
 # one-step run, each in its own rocprofv3 invocation (counters never together with the stats run).
 #   usage (from the repo root, on the box):  bash tools/profile_c4.sh <tag>
 set -u
-tag=${1:-r01_e}
+tag=${1:-r02_f}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
@@ -16,5 +16,6 @@ for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
 done
 cd $root
 python3 tools/pmc_summary.py "C4 exact, K=1024, T=10, tile width 32 (bench.py --config C4)" $out/pmc_summary.json $out/traffic_C4.json $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_TCC_HIT_sum > $out/pmc_print.log
+cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 find $out -name "*kernel_stats.csv" | head -3
 cat $out/bench_under_rocprof.json | tail -1 | cut -c1-600

@@ -11,7 +11,10 @@ no, U, I, E, K = synth.CONFIGS[cfg]
 g = synth.bipartite(no, U, I, E)
 flat = {k: g[k] for k in ("node_id", "node_type", "rowptr", "dst", "etype", "w")}
 G = Graph.from_flat(**flat, profile=True, mode=mode); G.buildGraph()
-n = U + I; nnz = int(g["rowptr"][-1]); alg = synth.algorithmic_bytes_per_step(n, nnz, 1, 8)
+n = U + I; nnz = int(g["rowptr"][-1])
+# value-free path (uniform row weights): no per-entry value, + the n*8-byte scale vector
+uni = bool(G.stats()["uniform_path"])
+alg = synth.algorithmic_bytes_per_step(n, nnz, 1, 0 if uni else 8) + (8 * n if uni else 0)
 rec = Recommender(G)
 for seed in (0, U // 2):
     rec.Recommendation(seed, 0.15, 10, 100)
