@@ -73,7 +73,7 @@ struct HandleKit {
     int device = -1;
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_h0 = nullptr, ev_h1 = nullptr;
-    void *pin = nullptr;
+    void *pin = nullptr, *stage = nullptr;
 };
 static std::mutex g_kit_mutex;
 static std::vector<HandleKit> g_kits;
@@ -102,6 +102,7 @@ static void kit_destroy(HandleKit &k)
     if (k.stream) (void)hipStreamDestroy(k.stream);
     if (k.stream2) (void)hipStreamDestroy(k.stream2);
     if (k.pin) (void)hipHostFree(k.pin);
+    if (k.stage) (void)hipHostFree(k.stage);
     k = HandleKit{};
 }
 static void kit_give(HandleKit &k)
@@ -213,6 +214,7 @@ int32_t rwr_graph_create(int32_t n, const int64_t *node_id, const uint8_t *node_
         g->ev_fork = kit.ev_fork; g->ev_join = kit.ev_join; g->ev_a = kit.ev_a; g->ev_b = kit.ev_b;
         g->ev_h0 = kit.ev_h0; g->ev_h1 = kit.ev_h1;
         g->sm_pin = kit.pin;
+        g->sm_stage = kit.stage;
     } else {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -269,6 +271,7 @@ int32_t rwr_graph_destroy(rwr_graph *g)
     kit.ev_h0 = g->ev_h0; kit.ev_h1 = g->ev_h1;
     kit.ev_fork = g->ev_fork; kit.ev_join = g->ev_join; kit.ev_a = g->ev_a; kit.ev_b = g->ev_b;
     kit.pin = g->sm_pin;
+    kit.stage = g->sm_stage;
     kit_give(kit);            // (parked for the next handle on this device, or destroyed when the pool is full)
     delete g;
     return RWR_OK;

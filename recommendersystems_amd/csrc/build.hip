@@ -10,7 +10,9 @@
 // the order in which Model.deliverRanks adds into nextRank[target] (Model.cs:78,85-88).
 #include "engine.h"
 
+#include <chrono>
 #include <cstdlib>
+#include <cstring>
 
 namespace rwr {
 
@@ -233,6 +235,58 @@ __global__ __launch_bounds__(256) void k_patch_links(int64_t count, const int64_
     if (new_w) w[p] = new_w[q];
 }
 
+// Ego-network-sized graphs: the six raw arrays arrive as ONE copy out of a pinned staging buffer and are dealt to their
+// device arrays by this kernel (six pageable copies cost ~100 us of a ~0.5 ms build); what the host needs back (link count,
+// flags, in_ptr, dangling) is written by k_stage_out straight into pinned host memory.
+constexpr int32_t STAGE_MAX_N = 8192;
+constexpr int64_t STAGE_MAX_M = 65536;
+constexpr size_t STAGE_OUT_OFF = 1u << 20;                                    // inputs below, outputs above
+constexpr size_t STAGE_BYTES = STAGE_OUT_OFF + 8 * (size_t)(STAGE_MAX_N + 1) + STAGE_MAX_N + 256;
+struct StageLayout { size_t id, rp, w, dst, nt, et, total; };
+static StageLayout stage_layout(int32_t n, int64_t m)
+{
+    StageLayout L;
+    L.id = 0;
+    L.rp = L.id + 8 * (size_t)n;
+    L.w = L.rp + 8 * ((size_t)n + 1);
+    L.dst = L.w + 8 * (size_t)m;
+    L.nt = L.dst + ((4 * (size_t)m + 7) & ~(size_t)7);
+    L.et = L.nt + (((size_t)n + 7) & ~(size_t)7);
+    L.total = L.et + (size_t)m;
+    return L;
+}
+__global__ __launch_bounds__(256) void k_stage_in(int32_t n, int64_t m, const uint8_t *__restrict__ st, StageLayout L,
+                                                  int64_t *__restrict__ node_id, uint8_t *__restrict__ node_type,
+                                                  int64_t *__restrict__ rowptr, int32_t *__restrict__ dst,
+                                                  uint8_t *__restrict__ etype, double *__restrict__ w)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        node_id[i] = reinterpret_cast<const int64_t *>(st + L.id)[i];
+        node_type[i] = st[L.nt + i];
+    }
+    if (i <= n) rowptr[i] = reinterpret_cast<const int64_t *>(st + L.rp)[i];
+    if (i < m) {
+        w[i] = reinterpret_cast<const double *>(st + L.w)[i];
+        dst[i] = reinterpret_cast<const int32_t *>(st + L.dst)[i];
+        etype[i] = st[L.et + i];
+    }
+}
+// out: [0] link count (int64), [8..24) flags, [32 ...) in_ptr (n+1 int64) when `full`, then dangling (n bytes)
+__global__ __launch_bounds__(256) void k_stage_out(int32_t n, const int64_t *__restrict__ in_ptr, const int *__restrict__ flags,
+                                                   const uint8_t *__restrict__ dangling, uint8_t *__restrict__ out, int full)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        reinterpret_cast<int64_t *>(out)[0] = in_ptr[n];
+        for (int q = 0; q < 4; ++q) reinterpret_cast<int *>(out + 8)[q] = flags[q];
+    }
+    if (full) {
+        if (i <= n) reinterpret_cast<int64_t *>(out + 32)[i] = in_ptr[i];
+        if (i < n) (out + 32 + 8 * ((size_t)n + 1))[i] = dangling[i];
+    }
+}
+
 static int bit_length(uint64_t v)
 {
     int b = 0;
@@ -242,6 +296,14 @@ static int bit_length(uint64_t v)
 
 static int32_t graph_derive(rwr_graph *g, bool first);
 
+static double bt_now()
+{
+    using namespace std::chrono;
+    return duration<double, std::micro>(steady_clock::now().time_since_epoch()).count();
+}
+static const bool bt_on = [] { const char *e = getenv("RWR_BUILD_TIMING"); return e && atoi(e) != 0; }();
+#define BT(label) do { if (bt_on) { const double t__ = bt_now(); fprintf(stderr, "[build] %-28s %8.1f us\n", label, t__ - bt_t); bt_t = t__; } } while (0)
+
 // uploads the RAW lists (they stay resident: the exclusion list reads them, Recommender.cs:20-24, and an incremental
 // rebuild re-derives everything else from them), then derives the walk's data
 int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_type, const int64_t *rowptr,
@@ -250,6 +312,7 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     const int32_t n = g->n;
     const int64_t m = g->nnz_raw;
     hipStream_t s = g->stream;
+    double bt_t = bt_now();
     if (m >= 0xFFFFFFFFll) {
         set_error("rwr_graph_create: %lld links exceed this build's per-device limit of 2^32-2", (long long)m);
         return RWR_E_UNSUPPORTED;
@@ -287,14 +350,38 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     RWR_TRY(g->item_order.alloc(n_items));
     RWR_TRY(g->item_rows.alloc(n_items));
 
-    RWR_HIP(hipMemcpyAsync(g->node_id.p, node_id, sizeof(int64_t) * n, hipMemcpyHostToDevice, s));
-    RWR_HIP(hipMemcpyAsync(g->node_type.p, node_type, (size_t)n, hipMemcpyHostToDevice, s));
-    RWR_HIP(hipMemcpyAsync(g->rowptr.p, rowptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
-    if (m > 0) {
-        RWR_HIP(hipMemcpyAsync(g->dst.p, dst, sizeof(int32_t) * m, hipMemcpyHostToDevice, s));
-        RWR_HIP(hipMemcpyAsync(g->etype.p, etype, (size_t)m, hipMemcpyHostToDevice, s));
-        RWR_HIP(hipMemcpyAsync(g->w_raw.p, w, sizeof(double) * m, hipMemcpyHostToDevice, s));
+    BT("host prep + allocs");
+    static const int stage_env = [] { const char *e = getenv("RWR_STAGE"); return e ? atoi(e) : 1; }();
+    g->staged = stage_env && n <= STAGE_MAX_N && m <= STAGE_MAX_M;
+    if (g->staged) {
+        if (!g->sm_stage) RWR_HIP(hipHostMalloc(&g->sm_stage, STAGE_BYTES, hipHostMallocMapped | hipHostMallocPortable));
+        const StageLayout L = stage_layout(n, m);
+        uint8_t *st = static_cast<uint8_t *>(g->sm_stage);
+        memcpy(st + L.id, node_id, 8 * (size_t)n);
+        memcpy(st + L.rp, rowptr, 8 * ((size_t)n + 1));
+        memcpy(st + L.nt, node_type, (size_t)n);
+        if (m > 0) {
+            memcpy(st + L.w, w, 8 * (size_t)m);
+            memcpy(st + L.dst, dst, 4 * (size_t)m);
+            memcpy(st + L.et, etype, (size_t)m);
+        }
+        RWR_TRY(g->d_stage.ensure(L.total + 8));
+        RWR_HIP(hipMemcpyAsync(g->d_stage.p, st, L.total, hipMemcpyHostToDevice, s));
+        const int64_t work = (m > (int64_t)n + 1) ? m : (int64_t)n + 1;
+        hipLaunchKernelGGL(k_stage_in, dim3(cdiv((size_t)work, 256)), dim3(256), 0, s, n, m, g->d_stage.p, L, g->node_id.p,
+                           g->node_type.p, g->rowptr.p, g->dst.p, g->etype.p, g->w_raw.p);
+        RWR_HIP(hipGetLastError());
+    } else {
+        RWR_HIP(hipMemcpyAsync(g->node_id.p, node_id, sizeof(int64_t) * n, hipMemcpyHostToDevice, s));
+        RWR_HIP(hipMemcpyAsync(g->node_type.p, node_type, (size_t)n, hipMemcpyHostToDevice, s));
+        RWR_HIP(hipMemcpyAsync(g->rowptr.p, rowptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
+        if (m > 0) {
+            RWR_HIP(hipMemcpyAsync(g->dst.p, dst, sizeof(int32_t) * m, hipMemcpyHostToDevice, s));
+            RWR_HIP(hipMemcpyAsync(g->etype.p, etype, (size_t)m, hipMemcpyHostToDevice, s));
+            RWR_HIP(hipMemcpyAsync(g->w_raw.p, w, sizeof(double) * m, hipMemcpyHostToDevice, s));
+        }
     }
+    BT("H2D enqueue");
     return graph_derive(g, true);
 }
 
@@ -341,6 +428,7 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     const int64_t m = g->nnz_raw;
     const int32_t n_items = g->n_items;
     hipStream_t s = g->stream;
+    double bt_t = bt_now();
     DevBuf<int32_t> esrc;
     DevBuf<uint32_t> skey, skey2, sval, sval2;
     DevBuf<uint8_t> temp;
@@ -360,6 +448,7 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     int h_flags[4] = {0, 0, 0, 0};   // [0] some row non-uniform, [1] bad target, [2] max in-degree, [3] a weight or row sum not in (0, inf)
     RWR_HIP(hipMemsetAsync(flags.p, 0, sizeof(h_flags), s));
 
+    BT("derive allocs");
     hipEvent_t e0 = g->ev_a, e1 = g->ev_b;
     RWR_HIP(hipEventRecord(e0, s));
 
@@ -376,9 +465,21 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     hipLaunchKernelGGL(k_in_ptr, dim3(cdiv((size_t)m + 1, 256)), dim3(256), 0, s, k_sorted, m, n, g->in_ptr.p);
     RWR_HIP(hipGetLastError());
     int64_t nnz = 0;
-    RWR_HIP(hipMemcpyAsync(&nnz, g->in_ptr.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    RWR_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+    const bool staged = g->staged && g->sm_stage;
+    uint8_t *pin_out = staged ? static_cast<uint8_t *>(g->sm_stage) + STAGE_OUT_OFF : nullptr;
+    if (staged) {
+        hipLaunchKernelGGL(k_stage_out, dim3(1), dim3(256), 0, s, n, g->in_ptr.p, flags.p, g->dangling.p, pin_out, 0);
+    } else {
+        RWR_HIP(hipMemcpyAsync(&nnz, g->in_ptr.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        RWR_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+    }
+    BT("enqueue row pass + link sort");
     RWR_HIP(hipStreamSynchronize(s));
+    if (staged) {
+        nnz = reinterpret_cast<const int64_t *>(pin_out)[0];
+        memcpy(h_flags, pin_out + 8, sizeof(h_flags));
+    }
+    BT("sync 1 (H2D + row pass + sort)");
     if (h_flags[1]) {
         set_error("rwr_graph_create: a link targets a node outside [0, %d)", n);
         return RWR_E_RANGE;
@@ -436,14 +537,28 @@ static int32_t graph_derive(rwr_graph *g, bool first)
         }
     }
     RWR_HIP(hipGetLastError());
-    RWR_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
-    RWR_HIP(hipEventRecord(e1, s));
-    RWR_HIP(hipStreamSynchronize(s));
-    g->max_in_deg = h_flags[2];
     g->h_in_ptr.resize((size_t)n + 1);
-    RWR_HIP(hipMemcpy(g->h_in_ptr.data(), g->in_ptr.p, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost));
     g->h_dangling.resize((size_t)n);
-    RWR_HIP(hipMemcpy(g->h_dangling.data(), g->dangling.p, (size_t)n, hipMemcpyDeviceToHost));
+    if (staged) {
+        hipLaunchKernelGGL(k_stage_out, dim3(cdiv((size_t)n + 1, 256)), dim3(256), 0, s, n, g->in_ptr.p, flags.p, g->dangling.p,
+                           pin_out, 1);
+        RWR_HIP(hipEventRecord(e1, s));
+        BT("enqueue gather + orders");
+        RWR_HIP(hipStreamSynchronize(s));
+        memcpy(h_flags, pin_out + 8, sizeof(h_flags));
+        memcpy(g->h_in_ptr.data(), pin_out + 32, sizeof(int64_t) * ((size_t)n + 1));
+        memcpy(g->h_dangling.data(), pin_out + 32 + 8 * ((size_t)n + 1), (size_t)n);
+        BT("sync 2 (orders)");
+    } else {
+        RWR_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+        RWR_HIP(hipEventRecord(e1, s));
+        BT("enqueue gather + orders");
+        RWR_HIP(hipStreamSynchronize(s));
+        BT("sync 2 (orders)");
+        RWR_HIP(hipMemcpy(g->h_in_ptr.data(), g->in_ptr.p, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost));
+        RWR_HIP(hipMemcpy(g->h_dangling.data(), g->dangling.p, (size_t)n, hipMemcpyDeviceToHost));
+    }
+    g->max_in_deg = h_flags[2];
     g->bin_end[0] = g->bin_end[1] = g->bin_end[2] = g->bin_huge = g->bin_hub = 0;
     static const int hub_t_env = [] { const char *e = getenv("RWR_HUB_T"); return e ? atoi(e) : 2048; }();   // (measured best on the MovieLens-shaped graph: 2048 / prefix 256)
     g->hub_t = hub_t_env < 128 ? 128 : hub_t_env;   // (hub rows are a prefix of the wave-per-row bin: >= 128 in-links)
@@ -462,6 +577,7 @@ static int32_t graph_derive(rwr_graph *g, bool first)
         g->x_bins[ph][1] += deg >= 32;
         g->x_bins[ph][2] += deg >= 4;
     }
+    BT("D2H in_ptr/dangling + bins");
     float ms = 0.f;
     RWR_HIP(hipEventElapsedTime(&ms, e0, e1));
     g->stats.build_ms = ms;

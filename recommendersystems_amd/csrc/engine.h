@@ -24,6 +24,7 @@ struct rwr_graph {
     int32_t nonneg = 1;      // every normalised weight is a finite number >= 0 (raw weights >= 0, row sums in (0, inf)): ranks stay
                              // >= 0, which the zero-skipping frontier paths and the binade scan rely on; otherwise the general kernels run
     int32_t max_in_deg = 0;
+    int32_t staged = 0;      // ego-network-sized graph: raw arrays arrived through the pinned staging buffer (build.hip)
     int32_t poisoned = 0;    // a failed incremental rebuild left raw and derived arrays out of step: every entry point refuses
     // rows of row_order (in-degree descending) with in-degree >= 128 / >= 32 / >= 4: lane-width bins of the K = 1 vector SpMV
     int32_t bin_end[3] = {0, 0, 0};
@@ -73,6 +74,8 @@ struct rwr_graph {
     rwr::DevBuf<double> X, Y;         // rank matrices [tile][n][G]
     rwr::DevBuf<int32_t> sm_tab;      // small.hip: places of the seed row's addends (per call)
     void *sm_pin = nullptr;           // small.hip: pinned host buffer the one-launch kernel writes the ranked list into
+    void *sm_stage = nullptr;         // build.hip: pinned staging buffer of an ego-network-sized graph's upload / read-back
+    rwr::DevBuf<uint8_t> d_stage;     // ... and its device-side landing area
     int32_t sm_pin_count = -1;        // >= 0: the last single-seed call left its list (that many entries) in sm_pin
     rwr::DevBuf<double> Z0, Z1;       // value-free path: z = ((1-d) x) * w_src of the current / next ranks, same layout
     rwr::DevBuf<int32_t> d_seeds;     // [tile][G], -1 = padding lane

@@ -36,6 +36,8 @@ while time.time() < t_end:
     params = dict(seed=int(rng.integers(0, 2 ** 31)), n_users=nu, n_items=ni, n_likes=int(rng.integers(0, 6 * (nu + ni))),
                   n_etc=int(rng.choice([0, 0, 7, 60])), p_undefined=float(rng.choice([0.0, 0.05, 0.4])),
                   n_friend=int(rng.integers(0, 2 * nu)), n_mention=int(rng.integers(0, nu)), n_author=int(rng.integers(0, nu)))
+    if rng.random() < 0.3:     # unit weights only, nothing relabelled: the value-free matrix path
+        params.update(uniform=True, n_mention=0)
     g = gg.random_graph(**params)
     n = len(g["node_id"])
     F = FlatGraph(**g)
