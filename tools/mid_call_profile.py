@@ -1,0 +1,21 @@
+"""One mid-size ego network (12 K nodes, 195 K links), the single-seed call repeated (for rocprofv3 --kernel-trace --stats)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from recommendersystems_amd import synth                                  # noqa: E402
+from recommendersystems_amd.rwr_based import Graph, Recommender           # noqa: E402
+
+U, I, E = (2000, 10000, 100000) if len(sys.argv) < 2 or sys.argv[1] == "12k" else (20000, 100000, 1000000)
+g = synth.bipartite(9, U, I, E)
+flat = {k: g[k] for k in ("node_id", "node_type", "rowptr", "dst", "etype", "w")}
+G = Graph.from_flat(**flat)
+G.buildGraph()
+rec = Recommender(G)
+N = 50
+rec.RecommendationArrays(0, 0.15, 10)
+t = time.perf_counter()
+for _ in range(N):
+    rec.RecommendationArrays(0, 0.15, 10)
+print(f"n={U + I}: call {(time.perf_counter() - t) / N * 1e6:.0f} us", flush=True)
