@@ -780,3 +780,52 @@ def test_fewer_links_than_nodes(amd):
     ids, sc, cnt = amd.Recommender(G).RecommendationBatch(seeds, 0.15, 6, 30)
     oi, os_, oc = F.recommend_batch(seeds, 0.15, 6, 30)
     assert (cnt == oc).all() and (ids == oi).all() and (bits(sc) == bits(os_)).all()
+
+
+@pytest.mark.parametrize("uniform", [True, False], ids=["value-free", "weighted"])
+def test_hub_row_exact_reduction_adversarial(amd, uniform):
+    """A row of thousands of in-links is summed by the exact PARALLEL reduction of pf.h (spmv.hip: k_spmv_exact_hub) and
+    must equal the reference's strictly sequential sum (Model.cs:85-88) bit for bit -- also when addends are exact halves
+    of the running sum's ulp (ties to even, parity-dependent), when the sum crosses many binades, and across zeros and
+    subnormals.  5 000 users each LIKE item 0 (one out-link each: weight 1); d = 0.5f, so the addend of user u is exactly
+    rank[u] / 2, and the host puts adversarial values into the public rank vector before deliverRanks()."""
+    U = 5000
+    n = U + 2
+    node_id = np.arange(100, 100 + n, dtype=np.int64)
+    node_type = np.array([gg.NODE_USER] * U + [gg.NODE_ITEM] * 2, dtype=np.uint8)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    dst, w = [], []
+    for u in range(U):
+        dst.append(U)                       # u -> item 0
+        w.append(1.0)
+        if not uniform and u == 7:          # one row with two different weights: the graph takes the weighted kernels
+            dst.append(U + 1)
+            w.append(3.0)
+        rowptr[u + 1] = len(dst)
+    rowptr[U + 1:] = len(dst)
+    g = dict(node_id=node_id, node_type=node_type, rowptr=rowptr, dst=np.array(dst, dtype=np.int32),
+             etype=np.ones(len(dst), dtype=np.uint8), w=np.array(w, dtype=np.float64))
+    G = dev_graph(amd, g)
+    assert G.stats()["uniform_path"] == (1 if uniform else 0)
+    F = FlatGraph(**g)
+    rng = np.random.default_rng(2024)
+    for trial in range(6):
+        kind = trial % 3
+        if kind == 0:      # a large head, then thousands of exact half-ulps and near-halves of it
+            x = rng.choice([2.0 ** -51, 3 * 2.0 ** -52, 2.0 ** -52, 5 * 2.0 ** -53, 0.0], size=U)
+            x[0] = 2.0
+        elif kind == 1:    # binade crossings all the way: magnitudes spread over 70 binades
+            x = np.ldexp(1.0 + rng.integers(0, 4, U) / 4.0, rng.integers(-60, 10, U).astype(np.int32))
+        else:              # subnormal and tiny addends first, zeros in between, normal ones later
+            x = np.concatenate([np.full(U // 2, 5e-324) * rng.integers(0, 9, U // 2), rng.random(U - U // 2) * 2.0 ** -1000])
+            x[rng.integers(0, U, 50)] = 1.0
+        m = amd.Model(G, 0.5, 3)
+        m.rank = np.concatenate([x, [0.0, 0.0]])
+        m.deliverRanks()
+        # the reference's sum, one add at a time in source order (Python floats are binary64)
+        wcol = g["w"][g["rowptr"][:U]] / np.array([g["w"][g["rowptr"][u]:g["rowptr"][u + 1]].sum() for u in range(U)])
+        acc = 0.0
+        for u in range(U):
+            acc += (0.5 * float(x[u])) * float(wcol[u])
+        assert bits([m.nextRank[U]])[0] == bits([acc])[0], (uniform, trial)
+    G.close()
