@@ -1182,11 +1182,21 @@ static int32_t ensure_workspace(rwr_graph *g, int G, int32_t K, int *TG_out)
     if (TG > 65535 / G) TG = 65535 / G;   // grid.y of the per-slot kernels is TG * G
     // exact mode: every tile's chain workgroup must be resident beside the SpMM (one per CU, see k_gate)
     if (g->opts.mode != RWR_MODE_FAST && g->opts.tile_group <= 0 && TG > 192) TG = 192;
-    RWR_TRY(g->X.ensure((size_t)TG * n * G));
-    RWR_TRY(g->Y.ensure((size_t)TG * n * G));
-    if (g->vf) {
-        RWR_TRY(g->Z0.ensure((size_t)TG * n * G));
-        RWR_TRY(g->Z1.ensure((size_t)TG * n * G));
+    // the rank matrices: if the device cannot give what the sizing above asked for (other handles of the process -- the
+    // reference runs up to ten host threads, Program.cs:11 -- may have taken their share since hipMemGetInfo was read),
+    // halve the tile group and try again instead of failing the call
+    for (;;) {
+        int32_t rc = g->X.ensure((size_t)TG * n * G);
+        if (rc == RWR_OK) rc = g->Y.ensure((size_t)TG * n * G);
+        if (rc == RWR_OK && g->vf) {
+            rc = g->Z0.ensure((size_t)TG * n * G);
+            if (rc == RWR_OK) rc = g->Z1.ensure((size_t)TG * n * G);
+        }
+        if (rc == RWR_OK) break;
+        if (rc != RWR_E_NOMEM || TG <= 1 || g->opts.tile_group > 0) return rc;
+        (void)hipGetLastError();
+        g->X.release(); g->Y.release(); g->Z0.release(); g->Z1.release();
+        TG = (TG + 1) / 2;
     }
     RWR_TRY(g->d_seeds.ensure((size_t)ntiles * G));
     RWR_TRY(g->d_part.ensure((size_t)TG * RP_GRID * G));
