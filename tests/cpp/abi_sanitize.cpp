@@ -44,7 +44,7 @@ int main()
         std::vector<double> w((size_t)m);
         int64_t p = 0;
         for (int i = 0; i < n; ++i)
-            for (int32_t t : out[i]) { dst[p] = t; et[p] = (rng() % 20 == 0) ? RWR_EDGE_UNDEFINED : RWR_EDGE_LIKE; w[p] = 1.0 + (double)(rng() % 4); ++p; }
+            for (int32_t t : out[i]) { dst[p] = t; et[p] = (rng() % 20 == 0) ? RWR_EDGE_UNDEFINED : RWR_EDGE_LIKE; w[p] = (round & 1) ? 1.0 : 1.0 + (double)(rng() % 4); ++p; }   // (odd rounds: unit weights = the value-free path)
         rwr_opts o{};
         o.struct_size = sizeof(o);
         o.device = -1;
@@ -66,6 +66,8 @@ int main()
         const int64_t full = cnt;
         if (full > 1) { int64_t small = 1; EXPECT_FAIL(rwr_recommend(g, U / 2, 0.15f, 6, 0, ids.data(), sc.data(), &small), RWR_E_CAPACITY); }
         EXPECT_FAIL(rwr_recommend(g, n, 0.15f, 6, 0, ids.data(), sc.data(), &cnt), RWR_E_RANGE);
+        cnt = n;
+        EXPECT_FAIL(rwr_recommend(g, 0, 1.5f, 6, 0, ids.data(), sc.data(), &cnt), RWR_E_UNSUPPORTED);   // damping factor outside [0, 1]
         // batch
         const int K = 1 + (int)(rng() % 70), top = 1 + (int)(rng() % 1200);
         std::vector<int32_t> seeds(K), counts(K);
