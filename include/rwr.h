@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RWR_VERSION_STRING "0.1.0"
+#define RWR_VERSION_STRING "0.2.0"
 
 /* status codes */
 enum {
