@@ -1096,13 +1096,25 @@ struct GroupIter {
         if (exact && serial) s2 = s;
         // (while X is sparse the bitmap-walking chain serves a whole tile at once; for a single seed the scan is cheaper)
         const bool scan_now = exact && scan && (!act || G == 1);
+        bool scan_side = false;
         if (scan_now) {
-            // parallel chain on the main stream, ahead of the SpMM (which skips the seed rows)
-            RWR_DISPATCH_G(G, launch_seed_terms<GG>(g, tg, X, d_seeds, c1, d_evoff, s, Zc));
+            // the parallel chain.  Batches: on the main stream, ahead of the SpMM (which skips the seed rows).  A single seed:
+            // on the second stream BESIDE the SpMV -- the two read the same vectors and write disjoint rows, and for one seed
+            // the chain's five small kernels take as long as the SpMV itself (C2: ~100 us each), so the step costs their
+            // maximum instead of their sum.
+            static const int side_env = [] { const char *e = getenv("RWR_SCAN_SIDE"); return e ? atoi(e) : 1; }();
+            scan_side = side_env && G == 1 && tg == 1 && s2 != s;
+            hipStream_t sc = scan_side ? s2 : s;
+            if (scan_side) {
+                RWR_HIP(hipEventRecord(g->ev_fork, s));
+                RWR_HIP(hipStreamWaitEvent(s2, g->ev_fork, 0));
+            }
+            RWR_DISPATCH_G(G, launch_seed_terms<GG>(g, tg, X, d_seeds, c1, d_evoff, sc, Zc));
             hipEvent_t c0 = nullptr, c1e = nullptr;
-            if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, s)); }
-            RWR_TRY(chain_scan_step(g, G, tg, X, Y, d_seeds, d_evoff, c1, nz_out, s));
-            if (prof) { RWR_HIP(hipEventRecord(c1e, s)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
+            if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, sc)); }
+            RWR_TRY(chain_scan_step(g, G, tg, X, Y, d_seeds, d_evoff, c1, nz_out, sc));
+            if (prof) { RWR_HIP(hipEventRecord(c1e, sc)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
+            if (scan_side) RWR_HIP(hipEventRecord(g->ev_join, s2));
             s2 = s;
         } else if (exact) {
             // fork: the seed-row chain runs beside the SpMM on the second stream
@@ -1133,7 +1145,7 @@ struct GroupIter {
         if (prof) { RWR_HIP(hipEventRecord(b, s)); spmm_ev.push_back(a); spmm_ev.push_back(b); g->spmm_ev_dense.push_back(nz_in ? 0 : 1); }
         if (!nz_in) { g->stats.spmm_dense_launches += 1; ++dense_steps; }
         if (exact) {
-            if (s2 != s && !scan_now) RWR_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
+            if ((s2 != s && !scan_now) || scan_side) RWR_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
         } else {
             RWR_DISPATCH_G(G, launch_restart_final<GG>(g, tg, Y, d_seeds, nz_out, s));
         }
