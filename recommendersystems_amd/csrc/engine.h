@@ -165,6 +165,7 @@ void launch_spmv_blocked(rwr_graph *g, const double *zin, double *Y, double *zou
                          bool fast, hipStream_t s);
 // small.hip: ego-network-sized graphs, one single-seed Recommendation as ONE kernel launch (bitwise the EXACT path's result)
 bool small_path_ok(const rwr_graph *g);
+bool small_path_seed_ok(const rwr_graph *g, int32_t seed);
 int32_t recommend_small(rwr_graph *g, int32_t seed, double d, int32_t n_iter, int32_t top_n, int64_t *ids, double *scores,
                         int32_t *count);
 // chain_scan.hip: the exact seed-row chain as a parallel binade scan

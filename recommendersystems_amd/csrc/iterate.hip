@@ -1291,7 +1291,7 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
             set_error("seed %d (batch position %d) is outside [0, %d)", seeds[k], k, n);
             return RWR_E_RANGE;
         }
-    if (K == 1 && small_path_ok(g)) {
+    if (K == 1 && small_path_ok(g) && small_path_seed_ok(g, seeds[0])) {
         // ego-network-sized graph, one seed (the unmodified harness's call, Experiment.cs:109): the whole call is one launch
         RWR_TRY(recommend_small(g, seeds[0], d, n_iter, top_n, ids, scores, counts));
         g->stats.seeds_done += 1;

@@ -242,6 +242,15 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_rwr(
     }
 }
 
+// the seed row's addend sequence (one restart addend per node + one addend per link INTO the seed; multi-edges can make
+// the latter exceed n) must fit the LDS array M
+bool small_path_seed_ok(const rwr_graph *g, int32_t seed)
+{
+    if (seed < 0 || seed >= g->n) return false;
+    const int64_t sdeg = g->h_in_ptr[(size_t)seed + 1] - g->h_in_ptr[(size_t)seed];
+    return (int64_t)g->n + sdeg <= (int64_t)SM_MCAP;
+}
+
 bool small_path_ok(const rwr_graph *g)
 {
     static const int env = [] { const char *e = getenv("RWR_SMALL"); return e ? atoi(e) : 1; }();

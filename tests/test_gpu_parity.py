@@ -829,3 +829,37 @@ def test_hub_row_exact_reduction_adversarial(amd, uniform):
             acc += (0.5 * float(x[u])) * float(wcol[u])
         assert bits([m.nextRank[U]])[0] == bits([acc])[0], (uniform, trial)
     G.close()
+
+
+def test_small_path_falls_back_when_the_seed_row_is_too_long(amd):
+    """The one-launch kernel of small.hip keeps the seed row's addend sequence (n restart addends + one addend per link
+    INTO the seed) in LDS.  Multi-edges (the loader de-duplicates on (target, type), DataLoader.cs:64-70) can make a seed's
+    in-list longer than n: such a call must take the general path and still equal the oracle bit for bit."""
+    U, I = 2100, 4000                                     # (<= 6144 nodes, <= 4096 items: the graph qualifies)
+    n = U + I
+    node_id = np.arange(n, dtype=np.int64) * 5 + 3
+    node_type = np.array([gg.NODE_USER] * U + [gg.NODE_ITEM] * I, dtype=np.uint8)
+    lists = [[] for _ in range(n)]
+    for v in range(I):                                   # every item links to user 0 twice (two types) and to one more user
+        lists[U + v] += [(0, gg.EDGE_LIKE, 1.0), (0, gg.EDGE_AUTHORSHIP, 2.0), (1 + v % (U - 1), gg.EDGE_LIKE, 1.0)]
+        lists[1 + v % (U - 1)].append((U + v, gg.EDGE_LIKE, 1.0))
+        if v % 7 == 0:
+            lists[0].append((U + v, gg.EDGE_LIKE, 1.0))
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    dst, et, w = [], [], []
+    for i in range(n):
+        for (t, y, wt) in lists[i]:
+            dst.append(t); et.append(y); w.append(wt)
+        rowptr[i + 1] = len(dst)
+    g = dict(node_id=node_id, node_type=node_type, rowptr=rowptr, dst=np.array(dst, dtype=np.int32),
+             etype=np.array(et, dtype=np.uint8), w=np.array(w, dtype=np.float64))
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g)
+    rec = amd.Recommender(G)
+    assert n + 2 * I > 2 * 6144                          # seed 0's sequence does not fit small.hip's LDS array
+    for seed in (0, 1):                                  # seed 0: 8 000 in-links (general path); seed 1: a few (one launch)
+        for T in (0, 3, 10):
+            got = rec.Recommendation(seed, 0.15, T)
+            ri, rs = F.recommend(seed, 0.15, T)
+            assert [r[0] for r in got] == ri.tolist() and (bits([r[1] for r in got]) == bits(rs)).all(), (seed, T)
+    G.close()
