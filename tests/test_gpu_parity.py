@@ -863,3 +863,34 @@ def test_small_path_falls_back_when_the_seed_row_is_too_long(amd):
             ri, rs = F.recommend(seed, 0.15, T)
             assert [r[0] for r in got] == ri.tolist() and (bits([r[1] for r in got]) == bits(rs)).all(), (seed, T)
     G.close()
+
+
+def test_error_paths_of_this_round(amd):
+    """Damping factor outside [0, 1] (ranks would go negative: the exclusion marker and the ranking keys assume scores >= 0)
+    is refused by the Recommendation entries with RWR_E_UNSUPPORTED while Model.run still follows the reference; the
+    row-partitioned step refuses to run before rwr_part_begin; a refused call leaves the handle usable."""
+    import ctypes as C
+    from recommendersystems_amd import _lib
+    g = gg.random_graph(5, n_users=50, n_items=200, n_likes=900, n_friend=40)
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g)
+    rec = amd.Recommender(G)
+    for bad in (1.5, -0.25, float("nan")):
+        with pytest.raises(amd.RwrError) as ei:
+            rec.Recommendation(0, bad, 5)
+        assert ei.value.status == _lib.RWR_E_UNSUPPORTED and "damping" in str(ei.value)
+        with pytest.raises(amd.RwrError) as ei:
+            rec.RecommendationBatch(np.array([0, 1], dtype=np.int32), bad, 5, 10)
+        assert ei.value.status == _lib.RWR_E_UNSUPPORTED
+    m = amd.Model(G, 1.5, 3)                              # d > 1: negative ranks, general kernels, still the reference's numbers
+    m.run(4)
+    r, _ = F.model_run(1.5, 3, 0, 4)
+    assert (bits(m.rank) == bits(r)).all()
+    lib = _lib.load()
+    buf = (C.c_double * (len(g["node_id"]) * 2))()
+    st = lib.rwr_part_step(G._handle(), C.cast(buf, C.c_void_p), C.cast(C.byref(buf, 8 * len(g["node_id"])), C.c_void_p), None)
+    assert st == _lib.RWR_E_INVALID and b"rwr_part_begin" in lib.rwr_last_error()
+    got = rec.Recommendation(0, 0.15, 5)                  # the handle is still good
+    ri, rs = F.recommend(0, 0.15, 5)
+    assert [x[0] for x in got] == ri.tolist() and (bits([x[1] for x in got]) == bits(rs)).all()
+    G.close()
