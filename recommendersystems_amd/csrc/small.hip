@@ -34,6 +34,8 @@ constexpr int SM_MAX_ITEMS = 4096;             // candidates of the LDS sort
 constexpr int SM_MCAP = 2 * SM_MAX_N;
 constexpr int SM_R = 16;                       // addends per lane and pass of the exact reduction
 constexpr int SM_PASS = WAVE * SM_R;           // 1024 addends per pass
+constexpr int SM_SEQ = 256;                    // addends folded one by one before the passes start (the sum crosses a binade
+                                               // every few addends while it is small; measured best, as in k_spmv_exact_hub)
 
 struct SmCand {
     uint64_t hi, lo;
@@ -83,6 +85,9 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_rwr(
     extern __shared__ double sm_lds[];
     double *M = sm_lds;                                            // [SM_MCAP + SM_MCAP / 64 + 1] padded addend sequence
     double *prod = sm_lds + (SM_MCAP + SM_MCAP / 64 + 64);         // [SM_WAVES][2][WAVE] staging lines of the long rows
+    // per lane row (position in row_order): {list start, (row id << 17) | list length} -- read every step from LDS instead of
+    // chasing row_order -> in_ptr through global memory (two dependent round trips per row and step)
+    int2 *desc = reinterpret_cast<int2 *>(prod + (size_t)SM_WAVES * 2 * WAVE);   // [SM_MAX_N]
     __shared__ int cnt_s;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
 
@@ -94,17 +99,30 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_rwr(
     const int32_t mlen = n + sdeg;
     // tab[i] = place of node i's restart addend: i + (number of links into the seed with source <= i);
     // tab[n + q] = place of link q: (its source) + q -- the restart addends of all earlier nodes and the links before it
+    // (the seed's in-list sources are parked in LDS for the bisections: M is not in use yet)
+    int32_t *ssrc = reinterpret_cast<int32_t *>(M);
+#pragma unroll 1
+    for (int32_t q = tid; q < sdeg; q += SM_THREADS) {
+        const int32_t sq = in_src[sp0 + q];
+        ssrc[q] = sq;
+        tab[n + q] = sq + q;
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int32_t i = tid; i < n; i += SM_THREADS) {
         int32_t lo = 0, hi = sdeg;
         while (lo < hi) {
             const int32_t mid = lo + ((hi - lo) >> 1);
-            if (in_src[sp0 + mid] <= i) lo = mid + 1; else hi = mid;
+            if (ssrc[mid] <= i) lo = mid + 1; else hi = mid;
         }
         tab[i] = i + lo;
     }
 #pragma unroll 1
-    for (int32_t q = tid; q < sdeg; q += SM_THREADS) tab[n + q] = in_src[sp0 + q] + q;
+    for (int32_t r = n_long + tid; r < n; r += SM_THREADS) {
+        const int32_t j = row_order[r];
+        const int64_t p = in_ptr[j];
+        desc[r] = make_int2((int)p, (int)(((uint32_t)j << 17) | (uint32_t)(in_ptr[j + 1] - p)));
+    }
     __syncthreads();
 
     for (int it = 0; it < n_iter; ++it) {
@@ -126,9 +144,9 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_rwr(
             double s = 0.0;
             if (dbg & 1) {
             } else if (scan_ok) {
-                const int first = mlen < SM_PASS ? mlen : SM_PASS;
+                const int first = mlen < SM_SEQ ? mlen : SM_SEQ;
                 s = sm_fold_seq(s, M, 0, first, lane);
-                for (int base = SM_PASS; base < mlen; base += SM_PASS)
+                for (int base = SM_SEQ; base < mlen; base += SM_PASS)
                     s = sm_fold_scan(s, M, base, (mlen - base) < SM_PASS ? (mlen - base) : SM_PASS, lane);
             } else {
                 s = sm_fold_seq(s, M, 0, mlen, lane);
@@ -167,10 +185,11 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_rwr(
                 if (lane == 0) Y[j] = acc;
             }
             for (int32_t r = n_long + (tid - WAVE); r < n; r += SM_THREADS - WAVE) {
-                const int32_t j = row_order[r];
+                const int2 dr = desc[r];
+                const int32_t j = (int32_t)((uint32_t)dr.y >> 17);
                 if (j == seed) continue;
-                int64_t p = in_ptr[j];
-                const int64_t e = in_ptr[j + 1];
+                int32_t p = dr.x;
+                const int32_t e = p + (int32_t)((uint32_t)dr.y & 0x1FFFFu);
                 double acc = 0.0;
                 for (; p + 4 <= e; p += 4) {
                     const int32_t i0 = in_src[p], i1 = in_src[p + 1], i2 = in_src[p + 2], i3 = in_src[p + 3];
@@ -274,7 +293,8 @@ int32_t recommend_small(rwr_graph *g, int32_t seed, double d, int32_t n_iter, in
     RWR_TRY(g->d_out_score.ensure((size_t)SM_MAX_ITEMS + 64));
     RWR_TRY(g->d_counts.ensure(64));
     RWR_TRY(g->sm_tab.ensure((size_t)SM_MCAP));
-    constexpr size_t smem = ((size_t)SM_MCAP + SM_MCAP / 64 + 64 + (size_t)SM_WAVES * 2 * WAVE) * sizeof(double);
+    constexpr size_t smem = ((size_t)SM_MCAP + SM_MCAP / 64 + 64 + (size_t)SM_WAVES * 2 * WAVE) * sizeof(double) +
+                            (size_t)SM_MAX_N * sizeof(int2);
     static_assert(smem >= (size_t)SM_MAX_ITEMS * sizeof(SmCand), "the sort re-uses the addend buffer");
     if (!g->sm_pin) {
         RWR_HIP(hipHostMalloc(&g->sm_pin, SM_MAX_ITEMS * 16 + 64, hipHostMallocMapped | hipHostMallocPortable));
