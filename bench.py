@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C4", help="tiny | C2 | C3 | C4 | C5 (BASELINE.md section 3)")
     ap.add_argument("--seeds-per-gpu", type=int, default=0)
-    ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--mode", default="exact", choices=["exact"])
     ap.add_argument("--tile-seeds", type=int, default=0)
     ap.add_argument("--tile-group", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -8,11 +8,13 @@ namespace Recommenders.RWRBased {
     public class Graph {
         public Dictionary<int, Node> nodes;
         public Dictionary<int, List<ForwardLink>> edges;
-        // PUBLIC FIELD as in the reference (Graph.cs:43).  buildGraph() fills it from the device for graphs of up to
-        // GraphFieldLimit raw links (every ego network of the harness); beyond that it stays null -- a field cannot be
-        // materialised lazily -- and LoadNormalizedGraph() fills it on request.  The harness never reads it.
+        // PUBLIC FIELD as in the reference (Graph.cs:43).  The harness never reads it (Experiment.cs:104-109 only calls
+        // buildGraph and Recommendation), and filling it costs two blocking device-to-host copies plus one ForwardLink[] per
+        // node on EVERY per-fold rebuild -- more than the device build itself for an ego network.  So it is opt-in: a host
+        // that does read the field sets GraphFieldLimit to the largest link count it wants filled eagerly by buildGraph()
+        // (a field cannot be materialised lazily), or calls LoadNormalizedGraph() when it needs it.  Default 0 = never.
         public Dictionary<int, ForwardLink[]> graph;
-        public static long GraphFieldLimit = 5000000;
+        public static long GraphFieldLimit = 0;
         internal GraphHandle handle;
         long[] rowptr; int[] dst; byte[] etype;
         long[] sentId; byte[] sentType; double[] sentW;   // what the device currently holds (for incremental rebuilds)
@@ -54,7 +56,7 @@ namespace Recommenders.RWRBased {
                 Native.Check(Native.rwr_graph_create(n, id, type, rowptr, dst, etype, w, ref opts, out handle));
             }
             sentId = id; sentType = type; sentW = w;
-            if (m <= GraphFieldLimit) LoadNormalizedGraph();
+            if (GraphFieldLimit > 0 && m <= GraphFieldLimit) LoadNormalizedGraph();
         }
 
         bool SameTopology(long[] id, byte[] type, long[] oldRowptr, int[] oldDst) {

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RWR_VERSION_STRING "0.2.0"
+#define RWR_VERSION_STRING "0.3.0"
 
 /* status codes */
 enum {
@@ -53,15 +53,12 @@ enum { RWR_NODE_UNDEFINED = 0, RWR_NODE_USER = 1, RWR_NODE_ITEM = 2, RWR_NODE_ET
 enum { RWR_EDGE_UNDEFINED = 0, RWR_EDGE_LIKE = 1, RWR_EDGE_FRIENDSHIP = 2, RWR_EDGE_FOLLOW = 3,
        RWR_EDGE_MENTION = 4, RWR_EDGE_AUTHORSHIP = 5, RWR_EDGE_PURCHASE = 6, RWR_EDGE_ETC = 7 };
 
-/* arithmetic mode of the power iteration */
-enum {
-    RWR_MODE_EXACT = 0,  /* every rank value is bitwise what Model.deliverRanks (Model.cs:76-100)
-                            computes: same addends, same order, no FMA contraction              */
-    RWR_MODE_FAST  = 1   /* the seed's own row gathers its restart mass by a tree reduction
-                            (re-associated); every other row is still summed in reference order.
-                            Scores within 1e-6 of EXACT; rankings identical except across
-                            score gaps below ~1e-12 relative                                      */
-};
+/* arithmetic mode of the power iteration.  There is one: every rank value is bitwise what
+ * Model.deliverRanks (Model.cs:76-100) computes -- same addends, same order, no FMA contraction -- and
+ * every ranked list is the reference's (Recommender.cs:35-38).  (Value 1 was RWR_MODE_FAST, a
+ * re-associated mode without a ranking guarantee; it was removed in ABI 3 and rwr_graph_create
+ * now rejects it with RWR_E_INVALID.) */
+enum { RWR_MODE_EXACT = 0 };
 
 /* rwr_model_run stop rule -- Model.run(int) / run(double) / run(): Model.cs:68-73,57-66,52-55 */
 enum { RWR_RUN_ITERATIONS = 0, RWR_RUN_THRESHOLD = 1, RWR_RUN_DEFAULT_THRESHOLD = 2 };
@@ -71,7 +68,7 @@ typedef struct rwr_graph rwr_graph;   /* opaque: device-resident graph + workspa
 typedef struct rwr_opts {
     int32_t struct_size;     /* = sizeof(rwr_opts); lets the struct grow compatibly            */
     int32_t device;          /* HIP device ordinal; -1 = env RWR_DEVICE, else current device   */
-    int32_t mode;            /* RWR_MODE_*; -1 = env RWR_MODE ("exact"/"fast"), else EXACT      */
+    int32_t mode;            /* RWR_MODE_EXACT; -1 = default (EXACT)                           */
     int32_t tile_seeds;      /* seeds per rank-matrix tile (lanes per row): 1,2,4,8,16,32,64;
                                 0 = auto                                                        */
     int32_t tile_group;      /* tiles iterated together (grid.y of the SpMM launch); 0 = auto  */
@@ -101,7 +98,7 @@ typedef struct rwr_stats {
     int64_t spmm_launches;
     int64_t spmm_seed_steps; /* sum over launches of (seeds in the launch) -- one unit = one
                                 power-iteration step of one seed                                */
-    double  chain_ms;        /* exact-mode seed-row kernel / fast-mode restart reduction        */
+    double  chain_ms;        /* seed-row kernels (sequential fold or binade scan)                */
     int64_t chain_launches;
     double  rank_ms;         /* exclusion mask + top-k / sort + gather                          */
     double  iterate_wall_ms; /* device time from the first to the last event of the iterate

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librwr.so")
 
 RWR_OK, RWR_E_INVALID, RWR_E_RANGE, RWR_E_NO_DEVICE, RWR_E_HIP, RWR_E_NOMEM, RWR_E_CAPACITY, RWR_E_UNSUPPORTED = range(8)
-RWR_MODE_EXACT, RWR_MODE_FAST = 0, 1
+RWR_MODE_EXACT = 0
 RWR_RUN_ITERATIONS, RWR_RUN_THRESHOLD, RWR_RUN_DEFAULT_THRESHOLD = 0, 1, 2
 
 # every symbol include/rwr.h declares (tests check that the library exports all of them)

@@ -177,15 +177,16 @@ int32_t rwr_graph_create(int32_t n, const int64_t *node_id, const uint8_t *node_
     }
     if (o.mode < 0) {
         const char *e = getenv("RWR_MODE");
-        o.mode = (e && strcmp(e, "fast") == 0) ? RWR_MODE_FAST : RWR_MODE_EXACT;
+        o.mode = (e && strcmp(e, "fast") == 0) ? 1 : RWR_MODE_EXACT;
     }
     if (o.device >= ndev) {
         set_error("rwr_graph_create: device %d requested but only %d visible", o.device, ndev);
         delete g;
         return RWR_E_NO_DEVICE;
     }
-    if (o.mode != RWR_MODE_EXACT && o.mode != RWR_MODE_FAST) {
-        set_error("rwr_graph_create: unknown mode %d", o.mode);
+    if (o.mode != RWR_MODE_EXACT) {
+        // (mode 1 was FAST until ABI 3: re-associated sums with no ranking guarantee and no speed advantage -- removed)
+        set_error("rwr_graph_create: unknown mode %d (the only arithmetic mode is RWR_MODE_EXACT = 0; FAST was removed)", o.mode);
         delete g;
         return RWR_E_INVALID;
     }
@@ -334,9 +335,8 @@ int32_t rwr_recommend(rwr_graph *g, int32_t seed, float d, int32_t n_iter, int32
     }
     if (cnt > 0 && g->sm_pin_count == cnt) {
         // ego-network-sized graph (small.hip): the kernel wrote the list into pinned host memory
-        const int64_t *pin_id = reinterpret_cast<const int64_t *>(g->sm_pin);
-        memcpy(out_id, pin_id, sizeof(int64_t) * (size_t)cnt);
-        memcpy(out_score, pin_id + 4096, sizeof(double) * (size_t)cnt);
+        memcpy(out_id, rwr::small_pin_ids(g), sizeof(int64_t) * (size_t)cnt);
+        memcpy(out_score, rwr::small_pin_scores(g), sizeof(double) * (size_t)cnt);
     } else if (cnt > 0) {
         RWR_HIP(hipMemcpyAsync(out_id, g->d_out_id.p, sizeof(int64_t) * (size_t)cnt, hipMemcpyDeviceToHost, g->stream));
         RWR_HIP(hipMemcpyAsync(out_score, g->d_out_score.p, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, g->stream));

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_order_keys_phase(int32_t n, const int64
     if (i >= n) return;
     const uint32_t deg = (uint32_t)(in_ptr[i + 1] - in_ptr[i]);
     const uint32_t phase = node_type[i] == RWR_NODE_ITEM ? 0u : 1u;
-    dkey[i] = (phase << top_bits) | (top - deg);
+    dkey[i] = (phase << top_bits) | (deg > top ? 0u : top - deg);   // (top_bits <= 31: the phase bit stays inside the key)
     dval[i] = (uint32_t)i;
 }
 
@@ -424,6 +424,8 @@ int32_t graph_update_links(rwr_graph *g, int64_t count, const int64_t *idx, cons
 // Graph.buildGraph + transpose + processing orders, from the device-resident raw lists
 static int32_t graph_derive(rwr_graph *g, bool first)
 {
+    g->part_G = 0;   // a row-partitioned run sized for the previous matrix is over: rwr_part_step asks for a new rwr_part_begin
+
     const int32_t n = g->n;
     const int64_t m = g->nnz_raw;
     const int32_t n_items = g->n_items;
@@ -489,7 +491,7 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     g->nonneg = h_flags[3] ? 0 : 1;
     static const int vf_env = [] { const char *e = getenv("RWR_VALUE_FREE"); return e ? atoi(e) : 1; }();
     g->vf = (g->uniform && g->nonneg && vf_env) ? 1 : 0;
-    RWR_TRY(g->in_src.ensure((size_t)nnz + 64));   // (padded: spmv_blocked.hip fetches up to 48 indices ahead of a row's end)
+    RWR_TRY(g->in_src.ensure((size_t)nnz + 64));   // (padded: wide index loads may run past a row's end)
     if (g->vf) g->in_w.release();
     else RWR_TRY(g->in_w.ensure((size_t)nnz));
     if (nnz > 0) {
@@ -516,9 +518,12 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, order_mode == 0 ? top_bits : 8, temp.p, s, &alt));
     hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p, g->row_order.p,
                        (int64_t)n);
+    // (from 2^31 links on the in-degree key is capped at 31 bits -- longer rows all sort first -- so that the phase bit fits)
+    const int ptop_bits = top_bits > 31 ? 31 : top_bits;
+    const uint32_t ptop = top_bits > 31 ? 0x7FFFFFFFu : top;
     hipLaunchKernelGGL(k_order_keys_phase, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->in_ptr.p, g->node_type.p, skey.p, sval.p,
-                       top, top_bits);
-    RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, top_bits + 1, temp.p, s, &alt));
+                       ptop, ptop_bits);
+    RWR_TRY(radix_sort_pairs<uint32_t>(skey.p, skey2.p, sval.p, sval2.p, (size_t)n, 1, ptop_bits + 1, temp.p, s, &alt));
     hipLaunchKernelGGL(k_u32_to_i32, dim3(cdiv(n, 256)), dim3(256), 0, s, alt ? sval2.p : sval.p, g->row_order_x.p,
                        (int64_t)n);
     if (first) {   // (the node arrays never change: an incremental rebuild keeps both item orders)
@@ -584,9 +589,6 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     g->stats.nnz = g->nnz;
     g->stats.uniform = g->uniform;
     g->stats.uniform_path = g->vf;
-    g->bk_state = 0;              // the blocked single-seed SpMV re-decides (and rebuilds its tables) on first use
-    g->bk_border.release();
-    g->bk_bp.release();
     return RWR_OK;
 }
 

@@ -28,7 +28,7 @@ struct rwr_graph {
     int32_t poisoned = 0;    // a failed incremental rebuild left raw and derived arrays out of step: every entry point refuses
     // rows of row_order (in-degree descending) with in-degree >= 128 / >= 32 / >= 4: lane-width bins of the K = 1 vector SpMV
     int32_t bin_end[3] = {0, 0, 0};
-    int32_t bin_huge = 0;    // rows with in-degree >= 2048: FAST: one 1024-thread workgroup per row; EXACT: k_spmv_exact_hub
+    int32_t bin_huge = 0;    // rows with in-degree >= 2048
     rwr_opts opts{};
 
     // node SoA (struct Node, Graph.cs:4-17)
@@ -64,12 +64,6 @@ struct rwr_graph {
     rwr::DevBuf<int32_t> item_order;  // ITEM rows by id descending
     rwr::DevBuf<int32_t> item_rows;   // ITEM rows by row index ascending
 
-    // single-seed SpMV on dense graphs with z staged through LDS (spmv_blocked.hip): 0 = not decided yet, 1 = tables built,
-    // -1 = this graph does not qualify; re-decided after every (re)build
-    int32_t bk_state = 0, bk_nblk = 0, bk_nhub = 0, bk_ngroups = 0, bk_nwg = 0;
-    rwr::DevBuf<int32_t> bk_border;   // rows: hub rows by in-degree descending, then the others likewise
-    rwr::DevBuf<int32_t> bk_bp;       // [nblk + 1][n]: entries of row border[pos] whose source is below the block's first node
-
     // batch workspace (lazily sized)
     rwr::DevBuf<double> X, Y;         // rank matrices [tile][n][G]
     rwr::DevBuf<int32_t> sm_tab;      // small.hip: places of the seed row's addends (per call)
@@ -80,7 +74,7 @@ struct rwr_graph {
     rwr::DevBuf<double> Z0, Z1;       // value-free path: z = ((1-d) x) * w_src of the current / next ranks, same layout
     rwr::DevBuf<int32_t> d_seeds;     // [tile][G], -1 = padding lane
     rwr::DevBuf<int32_t> d_slot_k;    // [tile][G]: batch position of the seed in this slot (-1 = padding)
-    rwr::DevBuf<double> d_part;       // fast mode: restart partial sums
+    rwr::DevBuf<double> d_part;       // partial sums of the deterministic tree reductions (global model, row-partitioned restart mass)
     rwr::DevBuf<unsigned int> d_gate;   // exact mode: check-in counter of the resident chain workgroups
     rwr::DevBuf<uint32_t> d_nz;       // [2][tile][ceil(n/32)] bitmaps: row of X / Y has a non-zero (first iterations)
     rwr::DevBuf<int64_t> d_evoff;     // exact mode: per seed slot, offset of its in-link terms in d_evterm
@@ -119,7 +113,7 @@ struct rwr_graph {
 namespace rwr {
 
 // Node count from which a graph counts as "beyond the L2s" (its rank vector no longer fits them): two-phase row order of
-// the single-seed SpMV, one more frontier iteration, FAST single seed on the list-order kernels, 32-seed tiles.
+// the single-seed SpMV, one more frontier iteration, 32-seed tiles.
 // RWR_BIG_N overrides the default of 2 M so that small test graphs can reach the same code paths.
 inline int32_t spmv_big_n()
 {
@@ -149,23 +143,18 @@ int32_t part_rank(rwr_graph *g, double *x, int32_t top_n, int64_t *ids, double *
 int32_t model_run(rwr_graph *g, int32_t seed, double d, int32_t run_mode, double value, double *rank_out,
                   int64_t *iters_out);
 int32_t model_deliver(rwr_graph *g, int32_t seed, double d, const double *rank_in, double *next_out);
-// spmv.hip: single-seed SpMV (EXACT: list-order sums, rows binned by in-degree; FAST: vector-CSR with tree reductions)
+// spmv.hip: single-seed SpMV (list-order sums, rows binned by in-degree)
 // (zin != nullptr: value-free form -- gathers zin, reads no per-entry value; zout (may be nullptr) receives the next z)
 // (hub_scan: every addend is known to be >= 0 and finite -- weights, ranks and 1-d -- so that rows of >= 2048 in-links may
 //  be summed by the exact parallel reduction of pf.h instead of one add at a time)
 void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *seeds, double c1, int skip,
                        const uint32_t *act, uint32_t *nz_out, hipStream_t s, const double *zin = nullptr,
                        double *zout = nullptr, bool hub_scan = false);
-void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hipStream_t s, const double *zin = nullptr,
-                        double *zout = nullptr);
-// spmv_blocked.hip: single-seed SpMV of dense value-free graphs, z staged through LDS block by block (bitwise the same sums)
-int32_t blocked_prepare(rwr_graph *g);
-bool blocked_ready(const rwr_graph *g);
-void launch_spmv_blocked(rwr_graph *g, const double *zin, double *Y, double *zout, const int32_t *seeds, int skip, double c1,
-                         bool fast, hipStream_t s);
 // small.hip: ego-network-sized graphs, one single-seed Recommendation as ONE kernel launch (bitwise the EXACT path's result)
 bool small_path_ok(const rwr_graph *g);
 bool small_path_seed_ok(const rwr_graph *g, int32_t seed);
+const int64_t *small_pin_ids(const rwr_graph *g);      // the list of the last recommend_small call, in pinned host memory
+const double *small_pin_scores(const rwr_graph *g);
 int32_t recommend_small(rwr_graph *g, int32_t seed, double d, int32_t n_iter, int32_t top_n, int64_t *ids, double *scores,
                         int32_t *count);
 // chain_scan.hip: the exact seed-row chain as a parallel binade scan

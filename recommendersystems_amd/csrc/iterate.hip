@@ -13,9 +13,8 @@
 //     pointer swap.
 // The seed's own row receives, besides its in-links, the restart mass of EVERY node
 // interleaved in node order (Model.cs:91-93,96-97): an n-term sequential fp64 chain per
-// seed.  EXACT mode reproduces that chain literally (k_seed_chain, one lane per seed, on a
-// second stream beside the SpMM); FAST mode sums the restart mass with a deterministic
-// tree (k_restart_partial/_final).
+// seed, reproduced literally (k_seed_chain, one lane per seed, on a
+// second stream beside the SpMM, or the parallel binade scan of chain_scan.hip).
 //
 // Arithmetic per edge is the reference's:  rw = (1-d)*x_i  (Model.cs:84), then
 // nextRank += rw * weight (Model.cs:87) -- two roundings, never an FMA (the file is built
@@ -228,124 +227,6 @@ __global__ __launch_bounds__(256) void k_spmm_chunked(int32_t n, const int64_t *
             const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << (sub * G));
             if (k == 0 && j >= 0 && (nzb & gmask)) atomicOr(&nz_out[(uint32_t)j >> 5], 1u << (j & 31));
         }
-    }
-}
-
-// Value-free, dense steps, V = 2 seeds per lane: every row gather is a 16-byte load (global_load_dwordx4), G / 2 lanes
-// share a destination row and a wave serves 128 / G rows at once -- half the vector-memory instructions and address
-// computations of the 8-byte form for the same bytes.  Same sums, same order: lane (row, k) owns seeds 2k and 2k+1.
-typedef double v2d_a __attribute__((ext_vector_type(2), aligned(16)));
-template <int G>
-__global__ __launch_bounds__(256) void k_spmm_vf_wide(int32_t n, const int64_t *__restrict__ in_ptr,
-                                                      const int32_t *__restrict__ in_src,
-                                                      const int32_t *__restrict__ row_order,
-                                                      const double *__restrict__ Z, double *__restrict__ Y,
-                                                      const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
-                                                      const double *__restrict__ w_src, double *__restrict__ Zout)
-{
-    static_assert(G >= 16 && G <= 64, "wide SpMM needs 16 <= G <= 64");
-    constexpr int L = G / 2;                 // lanes per destination row
-    constexpr int RPW = WAVE / L;            // rows per wave
-    constexpr int CH = L < 16 ? L : 16;      // entries per chunk = 16-byte gathers in flight per lane
-    const int tile = blockIdx.y;
-    const size_t toff = (size_t)tile * (size_t)n * G;
-    Z += toff;
-    Y += toff;
-    if (Zout) Zout += toff;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int sub = lane / L, k = lane % L;
-    const int gbase = (lane - k) << 2;
-    const int32_t seed0 = skip_seed_row ? seeds[tile * G + 2 * k] : -1;
-    const int32_t seed1 = skip_seed_row ? seeds[tile * G + 2 * k + 1] : -1;
-    const int wpb = blockDim.x / WAVE;
-    const int64_t nwaves = (int64_t)gridDim.x * wpb;
-    for (int64_t rb = ((int64_t)blockIdx.x * wpb + threadIdx.x / WAVE) * RPW; rb < n; rb += nwaves * RPW) {
-        const int64_t r = rb + sub;
-        int32_t j = -1;
-        int64_t p = 0, e = 0;
-        if (r < n) {
-            j = row_order[r];
-            p = in_ptr[j];
-            e = in_ptr[j + 1];
-        }
-        double a0 = 0.0, a1 = 0.0;
-        while (__any(p < e)) {
-            const int64_t left = e - p;
-            const int cnt = left > CH ? CH : (left > 0 ? (int)left : 0);
-            const int32_t my_idx = (k < cnt) ? in_src[p + k] : 0;
-            v2d_a xv[CH];
-#pragma unroll
-            for (int t = 0; t < CH; ++t) {
-                const int idx = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), my_idx);
-                if (t < cnt) xv[t] = *reinterpret_cast<const v2d_a *>(Z + (size_t)idx * G + 2 * k);
-                else xv[t] = v2d_a{0.0, 0.0};
-            }
-#pragma unroll
-            for (int t = 0; t < CH; ++t) {
-                if (t < cnt) { a0 += xv[t].x; a1 += xv[t].y; }     // the sources' z (Model.cs:84,87), list order
-            }
-            p += cnt;
-        }
-        if (j >= 0) {
-            const size_t at = (size_t)j * G + 2 * k;
-            const double ws = w_src[j];
-            if (j != seed0 && j != seed1) {
-                *reinterpret_cast<v2d_a *>(Y + at) = v2d_a{a0, a1};
-                if (Zout) { const double r0 = c1 * a0, r1 = c1 * a1; *reinterpret_cast<v2d_a *>(Zout + at) = v2d_a{r0 * ws, r1 * ws}; }
-            } else {
-                if (j != seed0) { Y[at] = a0; if (Zout) { const double r0 = c1 * a0; Zout[at] = r0 * ws; } }
-                if (j != seed1) { Y[at + 1] = a1; if (Zout) { const double r1 = c1 * a1; Zout[at + 1] = r1 * ws; } }
-            }
-        }
-    }
-}
-
-// TIMING-ONLY probe (RWR_SPMM_SLICE_PROBE, results are WRONG): the gather pattern of a source-sliced SpMM in which XCD x
-// only ever touches the rank-matrix rows of source slice x, so that the eight 4 MiB L2s cache eight different hot sets
-// instead of the same one.  Workgroup 8*rb + x (workgroups b and b + 8 share an XCD) walks the rows of row block rb and
-// gathers only the entries whose source lies in slice x; every row is thus visited by eight workgroups and the launch
-// performs exactly the gathers of the real kernel.  What a correct version would add on top -- the running sums handed
-// from slice to slice through Y in slice order -- is NOT here: this measures the best the scheme could do.
-struct SliceBounds { int32_t b[9]; };
-template <int G, int CH>
-__global__ __launch_bounds__(256) void k_spmm_slice_probe(int32_t n, const int64_t *__restrict__ in_ptr,
-                                                          const int32_t *__restrict__ in_src,
-                                                          const int32_t *__restrict__ row_order,
-                                                          const double *__restrict__ Z, double *__restrict__ Y, SliceBounds sb)
-{
-    constexpr int RPW = WAVE / G;
-    const int tile = blockIdx.y;
-    const size_t toff = (size_t)tile * (size_t)n * G;
-    Z += toff;
-    Y += toff;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int sub = lane / G, k = lane % G;
-    const int gbase = (lane - k) << 2;
-    const int x = blockIdx.x & 7;
-    const int32_t lo = sb.b[x], hi = sb.b[x + 1];
-    const int wpb = blockDim.x / WAVE;
-    const int64_t nwaves = (int64_t)(gridDim.x / 8) * wpb;
-    for (int64_t rb = ((int64_t)(blockIdx.x / 8) * wpb + threadIdx.x / WAVE) * RPW; rb < n; rb += nwaves * RPW) {
-        const int64_t r = rb + sub;
-        int32_t j = -1;
-        int64_t p = 0, e = 0;
-        if (r < n) { j = row_order[r]; p = in_ptr[j]; e = in_ptr[j + 1]; }
-        double acc = 0.0;
-        while (__any(p < e)) {
-            const int64_t left = e - p;
-            const int cnt = left > CH ? CH : (left > 0 ? (int)left : 0);
-            const int32_t my_idx = (k < cnt) ? in_src[p + k] : 0;
-            double xv[CH];
-#pragma unroll
-            for (int t = 0; t < CH; ++t) {
-                const int idx = __builtin_amdgcn_ds_bpermute(gbase + (t << 2), my_idx);
-                xv[t] = (t < cnt && idx >= lo && idx < hi) ? Z[(size_t)idx * G + k] : 0.0;
-            }
-#pragma unroll
-            for (int t = 0; t < CH; ++t) acc += xv[t];
-            p += cnt;
-        }
-        if (j >= 0 && x == 0) Y[(size_t)j * G + k] = acc;
     }
 }
 
@@ -688,57 +569,6 @@ __global__ __launch_bounds__(WAVE + CH3_NST) void k_seed_chain_roles(
     }
 }
 
-// FAST mode: restart mass R_k = sum_i (dangling_i ? x_i : x_i - (1-d) x_i), deterministic tree.
-constexpr int RP_BLOCK = 256;
-template <int G>
-__global__ __launch_bounds__(RP_BLOCK) void k_restart_partial(int32_t n, const uint8_t *__restrict__ dangling,
-                                                              const double *__restrict__ X,
-                                                              double *__restrict__ part, double c1)
-{
-    constexpr int RL = RP_BLOCK / G;   // row lanes per block
-    __shared__ double sh[RP_BLOCK];
-    const int tile = blockIdx.y;
-    const double *x = X + (size_t)tile * (size_t)n * G;
-    const int k = threadIdx.x % G, rl = threadIdx.x / G;
-    double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * RL + rl; i < n; i += (int64_t)gridDim.x * RL) {
-        double xi = x[(size_t)i * G + k];
-        double rw = c1 * xi;
-        acc += dangling[i] ? xi : (xi - rw);
-    }
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (int half = RL / 2; half >= 1; half >>= 1) {
-        if (rl < half) sh[threadIdx.x] += sh[threadIdx.x + half * G];
-        __syncthreads();
-    }
-    if (rl == 0) part[((size_t)tile * gridDim.x + blockIdx.x) * G + k] = sh[k];
-}
-
-template <int G>
-__global__ __launch_bounds__(64) void k_restart_final(int32_t n, int ntiles, int nblk, const double *__restrict__ part,
-                                                      double *__restrict__ Y, const int32_t *__restrict__ seeds,
-                                                      uint32_t *__restrict__ nz_out)
-{
-    // one wave per (tile, seed): lanes sum a strided share of the per-block partials, then a fixed butterfly
-    const int q = blockIdx.x;
-    if (q >= ntiles * G) return;
-    const int tile = q / G, k = q % G, lane = threadIdx.x;
-    const int32_t s = seeds[q];
-    if (s < 0) return;
-    double R = 0.0;
-    for (int b = lane; b < nblk; b += WAVE) R += part[((size_t)tile * nblk + b) * G + k];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) R += __shfl_xor(R, off, WAVE);
-    if (lane == 0) {
-        double *y = Y + (size_t)tile * (size_t)n * G + (size_t)s * G + k;
-        const double v = *y + R;
-        *y = v;
-        if (nz_out && v != 0.0)
-            atomicOr(&nz_out[(size_t)tile * (((size_t)n + 31) / 32) + ((uint32_t)s >> 5)], 1u << (s & 31));
-    }
-}
-
 // Model ctor, Model.cs:42-49: rank[seed] = nNodes, everything else 0
 // (value-free path: Z receives the seed's z, ((1-d) n) * w_src[seed])
 __global__ void k_init_seeds(int32_t n, int ntiles, int G, double *__restrict__ X,
@@ -810,52 +640,12 @@ static void launch_spmm(rwr_graph *g, int tg, const double *X, double *Y, const 
     unsigned gx = want < 8192u ? want : 8192u;
     static const int variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
     if constexpr (G == 1) {
-        // single seed, FAST mode: vector-CSR SpMV (re-associated sums are allowed there); EXACT keeps lane = row
-        // (the first iterations, while most rows are still exactly 0, run on the list-order kernels below, which
-        //  know how to skip rows without a non-zero in-neighbour: a list-order sum is a valid FAST result;
-        //  and so do graphs beyond the L2s, where the list-order kernels' two-phase row order beats the tree form)
-        if (g->opts.mode == RWR_MODE_FAST && tg == 1 && !skip && variant != 0 && !act && !nz_out && g->n < spmv_big_n()) {
-            launch_spmv_vector(g, X, Y, c1, s, Zin, Zout);
-            return;
-        }
         if (tg == 1 && variant != 0) {
             launch_spmv_exact(g, X, Y, seeds, c1, skip, act, nz_out, s, Zin, Zout, hub_scan);
             return;
         }
     }
-    if constexpr (G >= 16) {
-        // dense value-free steps: 16-byte gathers (two seeds per lane)
-        static const int wide = [] { const char *e = getenv("RWR_SPMM_WIDE"); return e ? atoi(e) : 0; }();
-        if (vf && wide && variant != 0 && !nz_in && !nz_out && !act) {
-            constexpr int RPW2 = WAVE / (G / 2);
-            const unsigned want2 = cdiv((size_t)g->n, (size_t)RPW2 * 4);
-            hipLaunchKernelGGL(k_spmm_vf_wide<G>, dim3(want2 < 8192u ? want2 : 8192u, tg), dim3(256), 0, s, g->n, g->in_ptr.p,
-                               g->in_src.p, g->row_order.p, GS, Y, seeds, c1, skip, g->w_src.p, Zout);
-            return;
-        }
-    }
     if constexpr (G >= 8) {
-        static const int probe = [] { const char *e = getenv("RWR_SPMM_SLICE_PROBE"); return e ? atoi(e) : 0; }();
-        if (probe && vf && !nz_in && !nz_out && !act) {   // timing-only experiment (see k_spmm_slice_probe): WRONG results
-            SliceBounds sb;
-            if (probe == 1) {
-                for (int q = 0; q <= 8; ++q) sb.b[q] = (int32_t)(((int64_t)g->n * q) / 8);
-            } else {   // equal gather mass per slice: a node is gathered once per out-link
-                const int64_t tot = g->h_rowptr[g->n];
-                int32_t i = 0;
-                sb.b[0] = 0;
-                for (int q = 1; q < 8; ++q) {
-                    while (i < g->n && g->h_rowptr[i] < tot * q / 8) ++i;
-                    sb.b[q] = i;
-                }
-                sb.b[8] = g->n;
-            }
-            constexpr int CHP = (G > 16 ? 16 : G);
-            const unsigned gxp = (gx & ~7u) ? (gx & ~7u) : 8u;
-            hipLaunchKernelGGL((k_spmm_slice_probe<G, CHP>), dim3(gxp, tg), dim3(256), 0, s, g->n, g->in_ptr.p, g->in_src.p,
-                               g->row_order.p, GS, Y, sb);
-            return;
-        }
         if (variant != 0) {
 #define RWR_SPMM_LAUNCH3(CH, CHK, WR, VFF)                                                                         \
     hipLaunchKernelGGL((k_spmm_chunked<G, CH, CHK, WR, VFF>), dim3(gx, tg), dim3(256), 0, s, g->n, g->in_ptr.p,    \
@@ -927,19 +717,7 @@ static void launch_chain(rwr_graph *g, int tg, const double *X, double *Y, const
                        g->in_src.p, g->in_w.p, g->dangling.p, X, Y, seeds, c1, nz_out);
 }
 constexpr int RP_GRID = 512;
-template <int G>
-static void launch_restart_partial(rwr_graph *g, int tg, const double *X, double c1, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_restart_partial<G>, dim3(RP_GRID, tg), dim3(RP_BLOCK), 0, s, g->n, g->dangling.p, X,
-                       g->d_part.p, c1);
-}
-template <int G>
-static void launch_restart_final(rwr_graph *g, int tg, double *Y, const int32_t *seeds, uint32_t *nz_out,
-                                 hipStream_t s)
-{
-    hipLaunchKernelGGL(k_restart_final<G>, dim3((unsigned)tg * G), dim3(64), 0, s, g->n, tg, RP_GRID,
-                       g->d_part.p, Y, seeds, nz_out);
-}
+constexpr int RP_BLOCK = 256;
 
 #define RWR_DISPATCH_G(G, CALL)                 \
     switch (G) {                                \
@@ -1063,12 +841,11 @@ struct GroupIter {
         chain_kind = sel == 1 ? 3 : sel == 2 ? 2 : sel == 3 ? 0 : chain_env;
         const double per_seed = 0.89 * (double)g->nnz / (double)(g->n > 0 ? g->n : 1) + 6.7;
         addends_nonneg = c1 >= 0.0 && c1 <= 1.0 && g->nonneg && ranks_nonneg;
-        scan = g->opts.mode != RWR_MODE_FAST && c1 >= 0.0 && c1 <= 1.0 && g->nonneg && ranks_nonneg &&
+        scan = c1 >= 0.0 && c1 <= 1.0 && g->nonneg && ranks_nonneg &&
                (chain_kind == 2 || (chain_kind == 1 && (double)tg * G * per_seed < scan_work));
         if (scan) RWR_TRY(chain_scan_prepare(g, G, tg, d_seeds, s));
-        if (Zc && G == 1 && tg == 1) RWR_TRY(blocked_prepare(g));   // single seed on a dense graph: LDS-blocked SpMV
         // (the simple one-lane reference kernel of the seed row walks the weighted in-lists itself)
-        if (Zc && g->opts.mode != RWR_MODE_FAST && chain_kind == 0 && !scan) RWR_TRY(ensure_in_w(g));
+        if (Zc && chain_kind == 0 && !scan) RWR_TRY(ensure_in_w(g));
         return RWR_OK;
     }
 
@@ -1077,7 +854,6 @@ struct GroupIter {
     {
         const int32_t n = g->n;
         hipStream_t s = g->stream, s2 = g->stream2;
-        const bool exact = g->opts.mode != RWR_MODE_FAST;
         const bool prof = g->opts.profile != 0;
         const size_t nzw = ((size_t)n + 31) / 32;
         constexpr int GATE_SLOTS = 64;
@@ -1093,9 +869,9 @@ struct GroupIter {
             hipLaunchKernelGGL(k_mark_active, dim3(cdiv(nzw, 4), tg), dim3(256), 0, s, n, nz_in, act, g->rowptr.p,
                                g->dst.p, g->etype.p);
         }
-        if (exact && serial) s2 = s;
+        if (serial) s2 = s;
         // (while X is sparse the bitmap-walking chain serves a whole tile at once; for a single seed the scan is cheaper)
-        const bool scan_now = exact && scan && (!act || G == 1);
+        const bool scan_now = scan && (!act || G == 1);
         bool scan_side = false;
         if (scan_now) {
             // the parallel chain.  Batches: on the main stream, ahead of the SpMM (which skips the seed rows).  A single seed:
@@ -1118,7 +894,7 @@ struct GroupIter {
             if (prof) { RWR_HIP(hipEventRecord(c1e, sc)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
             if (scan_side) RWR_HIP(hipEventRecord(g->ev_join, s2));
             s2 = s;
-        } else if (exact) {
+        } else {
             // fork: the seed-row chain runs beside the SpMM on the second stream
             RWR_DISPATCH_G(G, launch_seed_terms<GG>(g, tg, X, d_seeds, c1, d_evoff, s, Zc));
             gate_it = (use_gate && s2 != s) ? g->d_gate.p + (it % GATE_SLOTS) : nullptr;
@@ -1130,27 +906,18 @@ struct GroupIter {
             RWR_DISPATCH_G(G, launch_chain<GG>(g, tg, X, Y, d_seeds, c1, d_evoff, nz_out, gate_it, s2, act ? nz_in : nullptr, chain_kind));
             if (prof) { RWR_HIP(hipEventRecord(c1e, s2)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
             RWR_HIP(hipEventRecord(g->ev_join, s2));
-        } else {
-            hipEvent_t c0 = nullptr, c1e = nullptr;
-            if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, s)); }
-            RWR_DISPATCH_G(G, launch_restart_partial<GG>(g, tg, X, c1, s));
-            if (prof) { RWR_HIP(hipEventRecord(c1e, s)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
         }
-        if (exact && gate_it && !scan_now) {
+        if (gate_it && !scan_now) {
             const unsigned expected = (unsigned)(tg < 192 ? tg : 192);
             hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, gate_it, expected);
         }
         hipEvent_t a = nullptr, b = nullptr;
         if (prof) { a = pool.get(); b = pool.get(); RWR_HIP(hipEventRecord(a, s)); }
         double *zout = (Zc && !last) ? Zn : nullptr;
-        RWR_DISPATCH_G(G, launch_spmm<GG>(g, tg, X, Y, d_seeds, c1, exact ? 1 : 0, nz_in, nz_out, s, act, Zc, zout, addends_nonneg));
+        RWR_DISPATCH_G(G, launch_spmm<GG>(g, tg, X, Y, d_seeds, c1, 1, nz_in, nz_out, s, act, Zc, zout, addends_nonneg));
         if (prof) { RWR_HIP(hipEventRecord(b, s)); spmm_ev.push_back(a); spmm_ev.push_back(b); g->spmm_ev_dense.push_back(nz_in ? 0 : 1); }
         if (!nz_in) { g->stats.spmm_dense_launches += 1; ++dense_steps; }
-        if (exact) {
-            if ((s2 != s && !scan_now) || scan_side) RWR_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
-        } else {
-            RWR_DISPATCH_G(G, launch_restart_final<GG>(g, tg, Y, d_seeds, nz_out, s));
-        }
+        if ((s2 != s && !scan_now) || scan_side) RWR_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
         // value-free path: the seed rows' own z, now that the seed-row kernel has left their rank in Y
         if (zout) hipLaunchKernelGGL(k_seed_z, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, Y, zout, d_seeds, g->w_src.p, c1);
         RWR_HIP(hipGetLastError());
@@ -1186,6 +953,8 @@ static int32_t ensure_workspace(rwr_graph *g, int G, int32_t K, int *TG_out)
         RWR_HIP(hipMemGetInfo(&fr, &tot));
         // what is already held by the rank matrices counts as available
         fr += (g->X.count + g->Y.count + g->Z0.count + g->Z1.count) * sizeof(double);
+        // three quarters of what is free go to the rank matrices; the rest stays for the buffers sized after them (frontier
+        // bitmaps and seed slots below -- inside the retry loop --, chain-scan cells, ranking keys) and for other handles
         cap = fr / 2 + fr / 4;
     }
     const size_t mats = g->vf ? 4 : 2;   // X, Y (+ the value-free path's z of the current and of the next ranks)
@@ -1195,7 +964,7 @@ static int32_t ensure_workspace(rwr_graph *g, int G, int32_t K, int *TG_out)
     if (TG > ntiles) TG = ntiles;
     if (TG > 65535 / G) TG = 65535 / G;   // grid.y of the per-slot kernels is TG * G
     // exact mode: every tile's chain workgroup must be resident beside the SpMM (one per CU, see k_gate)
-    if (g->opts.mode != RWR_MODE_FAST && g->opts.tile_group <= 0 && TG > 192) TG = 192;
+    if (g->opts.tile_group <= 0 && TG > 192) TG = 192;
     // the rank matrices: if the device cannot give what the sizing above asked for (other handles of the process -- the
     // reference runs up to ten host threads, Program.cs:11 -- may have taken their share since hipMemGetInfo was read),
     // halve the tile group and try again instead of failing the call
@@ -1206,16 +975,15 @@ static int32_t ensure_workspace(rwr_graph *g, int G, int32_t K, int *TG_out)
             rc = g->Z0.ensure((size_t)TG * n * G);
             if (rc == RWR_OK) rc = g->Z1.ensure((size_t)TG * n * G);
         }
+        if (rc == RWR_OK) rc = g->d_seeds.ensure((size_t)ntiles * G);
+        if (rc == RWR_OK) rc = g->d_nz.ensure(3 * (size_t)TG * ((n + 31) / 32));   // X, Y non-zero rows + active destination rows
+        if (rc == RWR_OK) rc = g->d_gate.ensure(64);
         if (rc == RWR_OK) break;
         if (rc != RWR_E_NOMEM || TG <= 1 || g->opts.tile_group > 0) return rc;
         (void)hipGetLastError();
-        g->X.release(); g->Y.release(); g->Z0.release(); g->Z1.release();
+        g->X.release(); g->Y.release(); g->Z0.release(); g->Z1.release(); g->d_nz.release();
         TG = (TG + 1) / 2;
     }
-    RWR_TRY(g->d_seeds.ensure((size_t)ntiles * G));
-    RWR_TRY(g->d_part.ensure((size_t)TG * RP_GRID * G));
-    RWR_TRY(g->d_nz.ensure(3 * (size_t)TG * ((n + 31) / 32)));   // X, Y non-zero rows + active destination rows
-    RWR_TRY(g->d_gate.ensure(64));
     *TG_out = TG;
     return RWR_OK;
 }

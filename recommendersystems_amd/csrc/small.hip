@@ -80,7 +80,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_rwr(
     const int32_t *__restrict__ dst, const uint8_t *__restrict__ etype, const int32_t *__restrict__ item_rows,
     const int64_t *__restrict__ node_id, double *X, double *Y, int32_t *tab, int64_t *__restrict__ out_id,
     double *__restrict__ out_score, int32_t *__restrict__ out_count, int64_t *__restrict__ pin_id,
-    double *__restrict__ pin_score, int32_t *__restrict__ pin_count, int dbg)
+    double *__restrict__ pin_score, int32_t *__restrict__ pin_count)
 {
     extern __shared__ double sm_lds[];
     double *M = sm_lds;                                            // [SM_MCAP + SM_MCAP / 64 + 1] padded addend sequence
@@ -142,8 +142,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_rwr(
         if (wave == 0) {
             // ---- the seed's row: M folded in order (Model.cs:85-93,96-97)
             double s = 0.0;
-            if (dbg & 1) {
-            } else if (scan_ok) {
+            if (scan_ok) {
                 const int first = mlen < SM_SEQ ? mlen : SM_SEQ;
                 s = sm_fold_seq(s, M, 0, first, lane);
                 for (int base = SM_SEQ; base < mlen; base += SM_PASS)
@@ -152,7 +151,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_rwr(
                 s = sm_fold_seq(s, M, 0, mlen, lane);
             }
             if (lane == 0) Y[seed] = s;
-        } else if (!(dbg & 2)) {
+        } else {
             // ---- every other row, in-degree descending (row_order): long rows a wave each, the rest a lane each
             double *pb = prod + (size_t)wave * 2 * WAVE;
             int buf = 0;
@@ -270,6 +269,10 @@ bool small_path_seed_ok(const rwr_graph *g, int32_t seed)
     return (int64_t)g->n + sdeg <= (int64_t)SM_MCAP;
 }
 
+// layout of the pinned result buffer recommend_small leaves behind (rwr_recommend copies the list out of it)
+const int64_t *small_pin_ids(const rwr_graph *g) { return reinterpret_cast<const int64_t *>(g->sm_pin); }
+const double *small_pin_scores(const rwr_graph *g) { return reinterpret_cast<const double *>(small_pin_ids(g) + SM_MAX_ITEMS); }
+
 bool small_path_ok(const rwr_graph *g)
 {
     static const int env = [] { const char *e = getenv("RWR_SMALL"); return e ? atoi(e) : 1; }();
@@ -303,15 +306,12 @@ int32_t recommend_small(rwr_graph *g, int32_t seed, double d, int32_t n_iter, in
     int64_t *pin_id = reinterpret_cast<int64_t *>(g->sm_pin);
     double *pin_score = reinterpret_cast<double *>(pin_id + SM_MAX_ITEMS);
     int32_t *pin_count = reinterpret_cast<int32_t *>(pin_score + SM_MAX_ITEMS);
-    // timing diagnostics only (results are wrong with any bit set): 1 = skip the seed row's fold, 2 = skip the other rows,
-    // 4 = fold without the binade reduction
-    static const int dbg = [] { const char *e = getenv("RWR_SMALL_DBG"); return e ? atoi(e) : 0; }();
     const double c1 = 1 - d;                                       // Model.cs:84
-    const int scan_ok = (c1 >= 0.0 && c1 <= 1.0 && !(dbg & 4)) ? 1 : 0;   // ranks >= 0: the binade reduction's precondition
+    const int scan_ok = (c1 >= 0.0 && c1 <= 1.0) ? 1 : 0;   // ranks >= 0: the binade reduction's precondition
     hipLaunchKernelGGL(k_small_rwr, dim3(1), dim3(SM_THREADS), smem, s, n, g->n_items, g->bin_end[0], seed, c1, n_iter, top_n,
                        scan_ok, g->in_ptr.p, g->in_src.p, g->in_w.p, g->dangling.p, g->row_order.p, g->rowptr.p, g->dst.p,
                        g->etype.p, g->item_rows.p, g->node_id.p, g->X.p, g->Y.p, g->sm_tab.p, g->d_out_id.p, g->d_out_score.p,
-                       g->d_counts.p, pin_id, pin_score, pin_count, dbg);
+                       g->d_counts.p, pin_id, pin_score, pin_count);
     RWR_HIP(hipGetLastError());
     RWR_HIP(hipStreamSynchronize(s));
     const int32_t cnt = *pin_count;

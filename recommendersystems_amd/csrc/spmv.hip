@@ -1,7 +1,6 @@
 // K = 1: the SpMV of a single seed -- y = (1-d) P^T x  (Model.deliverRanks, Model.cs:78-88, one rank vector).
-//   EXACT: every row summed in the reference's addend order (bitwise); rows binned by in-degree so that long rows
-//          are served cooperatively (parallel loads / gathers / products, sequential adds);
-//   FAST : the classic vector-CSR form with shuffle-butterfly reductions (scores within 1e-6).
+// Every row is summed in the reference's addend order (bitwise); rows are binned by in-degree so that long rows
+// are served cooperatively (parallel loads / gathers / products, sequential adds).
 #include "engine.h"
 #include "pf.h"
 
@@ -323,131 +322,6 @@ __global__ __launch_bounds__(WAVE) void k_spmv_exact_hub(int32_t r0, int32_t r1,
     }
 }
 
-// K = 1, FAST mode: the classic vector-CSR SpMV.  W lanes share one destination row: each lane streams every W-th
-// entry of the row's in-list (coalesced index and weight reads), gathers x, keeps a private partial sum, and the W
-// partials are combined with a shuffle butterfly whose shape depends only on W -- rows of equal structure get
-// bit-identical results, so structural ties stay tied.  The summation order differs from the reference's, which is
-// why this kernel exists only in FAST mode (scores within 1e-6).  Rows are binned by in-degree (row_order is sorted
-// by it): W = 64 / 16 / 4 / 1.
-template <int W, bool VF>
-__global__ __launch_bounds__(256) void k_spmv_vector(int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
-                                                     const int32_t *__restrict__ in_src,
-                                                     const double *__restrict__ in_w,
-                                                     const int32_t *__restrict__ row_order,
-                                                     const double *__restrict__ x, double *__restrict__ y, double c1,
-                                                     const double *__restrict__ w_src, double *__restrict__ zout)
-{
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int l = (int)(gid % W);
-    for (int64_t r = r0 + gid / W; r < r1; r += ((int64_t)gridDim.x * blockDim.x) / W) {
-        const int32_t j = row_order[r];
-        const int64_t p0 = in_ptr[j], p1 = in_ptr[j + 1];
-        double acc = 0.0;
-        int64_t p = p0 + l;
-        for (; p + 3 * W < p1; p += 4 * W) {               // four independent gathers in flight per lane
-            if (VF) {
-                const double a0 = x[in_src[p]], a1 = x[in_src[p + W]], a2 = x[in_src[p + 2 * W]], a3 = x[in_src[p + 3 * W]];
-                acc += a0; acc += a1; acc += a2; acc += a3;
-            } else {
-                const double a0 = c1 * x[in_src[p]], a1 = c1 * x[in_src[p + W]];
-                const double a2 = c1 * x[in_src[p + 2 * W]], a3 = c1 * x[in_src[p + 3 * W]];
-                acc += a0 * in_w[p];
-                acc += a1 * in_w[p + W];
-                acc += a2 * in_w[p + 2 * W];
-                acc += a3 * in_w[p + 3 * W];
-            }
-        }
-        for (; p < p1; p += W) {
-            if (VF) acc += x[in_src[p]];
-            else acc += (c1 * x[in_src[p]]) * in_w[p];
-        }
-#pragma unroll
-        for (int off = W / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, W);
-        if (l == 0) {
-            y[j] = acc;
-            if (VF && zout) { const double rw = c1 * acc; zout[j] = rw * w_src[j]; }
-        }
-    }
-}
-
-// very long rows (in-degree >= 2048): a whole 1024-thread workgroup per row; per-lane partials, shuffle butterfly per
-// wave, then the 16 wave sums are staged in LDS and added in wave order
-template <bool VF>
-__global__ __launch_bounds__(1024) void k_spmv_row_block(int32_t r1, const int64_t *__restrict__ in_ptr,
-                                                         const int32_t *__restrict__ in_src,
-                                                         const double *__restrict__ in_w,
-                                                         const int32_t *__restrict__ row_order,
-                                                         const double *__restrict__ x, double *__restrict__ y, double c1,
-                                                         const double *__restrict__ w_src, double *__restrict__ zout)
-{
-    __shared__ double wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int32_t r = blockIdx.x; r < r1; r += gridDim.x) {
-        const int32_t j = row_order[r];
-        const int64_t p0 = in_ptr[j], p1 = in_ptr[j + 1];
-        double acc = 0.0;
-        int64_t p = p0 + tid;
-        for (; p + 3 * 1024 < p1; p += 4 * 1024) {
-            if (VF) {
-                const double a0 = x[in_src[p]], a1 = x[in_src[p + 1024]], a2 = x[in_src[p + 2048]], a3 = x[in_src[p + 3072]];
-                acc += a0; acc += a1; acc += a2; acc += a3;
-            } else {
-                const double a0 = c1 * x[in_src[p]], a1 = c1 * x[in_src[p + 1024]];
-                const double a2 = c1 * x[in_src[p + 2048]], a3 = c1 * x[in_src[p + 3072]];
-                acc += a0 * in_w[p];
-                acc += a1 * in_w[p + 1024];
-                acc += a2 * in_w[p + 2048];
-                acc += a3 * in_w[p + 3072];
-            }
-        }
-        for (; p < p1; p += 1024) {
-            if (VF) acc += x[in_src[p]];
-            else acc += (c1 * x[in_src[p]]) * in_w[p];
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane == 0) wsum[wv] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-            for (int q = 0; q < 16; ++q) t += wsum[q];
-            y[j] = t;
-            if (VF && zout) { const double rw = c1 * t; zout[j] = rw * w_src[j]; }
-        }
-        __syncthreads();
-    }
-}
-
-void launch_spmv_vector(rwr_graph *g, const double *x, double *y, double c1, hipStream_t s, const double *zin, double *zout)
-{
-    const int32_t n = g->n, bh = g->bin_huge, b0 = g->bin_end[0], b1 = g->bin_end[1], b2 = g->bin_end[2];
-    const bool vf = zin != nullptr;
-    if (vf && blocked_ready(g)) {          // dense graph: z staged through LDS (spmv_blocked.hip)
-        launch_spmv_blocked(g, zin, y, zout, nullptr, 0, c1, true, s);
-        return;
-    }
-    const double *gs = vf ? zin : x;       // gather source
-    auto grid = [](int64_t rows, int W) { int64_t blocks = (rows * W + 255) / 256; return (unsigned)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks)); };
-#define RWR_VEC(KERN, GRID, BLOCK, ...)                                                                      \
-    {                                                                                                        \
-        if (vf) hipLaunchKernelGGL((KERN<true>), GRID, BLOCK, 0, s, __VA_ARGS__, g->w_src.p, zout);          \
-        else hipLaunchKernelGGL((KERN<false>), GRID, BLOCK, 0, s, __VA_ARGS__, g->w_src.p, zout);            \
-    }
-#define RWR_VECW(W, GRID, ...)                                                                                           \
-    {                                                                                                                    \
-        if (vf) hipLaunchKernelGGL((k_spmv_vector<W, true>), GRID, dim3(256), 0, s, __VA_ARGS__, g->w_src.p, zout);      \
-        else hipLaunchKernelGGL((k_spmv_vector<W, false>), GRID, dim3(256), 0, s, __VA_ARGS__, g->w_src.p, zout);        \
-    }
-    if (bh > 0)
-        RWR_VEC(k_spmv_row_block, dim3(bh < 4096 ? bh : 4096), dim3(1024), bh, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, gs, y, c1)
-    if (b0 > bh) RWR_VECW(64, dim3(grid(b0 - bh, 64)), bh, b0, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, gs, y, c1)
-    if (b1 > b0) RWR_VECW(16, dim3(grid(b1 - b0, 16)), b0, b1, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, gs, y, c1)
-    if (b2 > b1) RWR_VECW(4, dim3(grid(b2 - b1, 4)), b1, b2, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, gs, y, c1)
-    if (n > b2) RWR_VECW(1, dim3(grid(n - b2, 1)), b2, n, g->in_ptr.p, g->in_src.p, g->in_w.p, g->row_order.p, gs, y, c1)
-#undef RWR_VEC
-#undef RWR_VECW
-}
-
 // EXACT single seed: two phases (ITEM rows, then the others -- engine.h: row_order_x), each binned by in-degree:
 // >= 128 in-links a wave per row; >= 32: 16 lanes per row; >= 4: 4 lanes per row; below: a lane per row
 // (RWR_GROUP_ROWS = 0 keeps everything under 128 on the lane-per-row form; RWR_ROW_ORDER != 0 or RWR_SPMV_PHASES = 0: one
@@ -462,10 +336,6 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
     static const int phases_env = [] { const char *e = getenv("RWR_SPMV_PHASES"); return e ? atoi(e) : -1; }();
     const int phases = phases_env >= 0 ? phases_env : (g->n >= spmv_big_n() ? 1 : 0);
     const bool vf = zin != nullptr;
-    if (vf && !act && !nz_out && blocked_ready(g)) {   // dense step of a dense graph: z staged through LDS (spmv_blocked.hip)
-        launch_spmv_blocked(g, zin, Y, zout, seeds, skip, c1, g->opts.mode == RWR_MODE_FAST && !skip, s);
-        return;
-    }
     const double *gs = vf ? zin : X;       // gather source
     // hub rows (>= hub_t in-links, first in the in-degree order): exact parallel reduction, one wave per row, on a stream of
     // its own beside the binned kernel (dense steps only, and only when every addend is known to be >= 0)

@@ -80,7 +80,7 @@ class Graph:
         self._graph_cache = None
         self._h = C.c_void_p()
         self._opts = _lib.rwr_opts(C.sizeof(_lib.rwr_opts), device,
-                                   {None: -1, "exact": _lib.RWR_MODE_EXACT, "fast": _lib.RWR_MODE_FAST}[mode],
+                                   {None: -1, "exact": _lib.RWR_MODE_EXACT}[mode],
                                    tile_seeds, tile_group, 1 if profile else 0, workspace_bytes,
                                    {None: 0, "auto": 0, "fold": 1, "scan": 2, "simple": 3}[seed_row_kernel], 0)
         self._flat = None

@@ -81,3 +81,43 @@ def test_header_is_plain_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
                            "-o", str(exe), "-L" + pkg, "-lrwr", "-Wl,-rpath," + pkg])
     assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_shipped_library_holds_no_wrong_result_knobs():
+    """Timing probes that trade correctness for a measurement (a source-sliced gather probe, 'skip this phase' debug
+    masks) once lived behind environment variables of the shipping library.  They are gone: nothing in the environment
+    may steer the drop-in .so into wrong answers, and the removed FAST mode has no kernels left."""
+    L = _lib()
+    blob = open(L.LIB_PATH, "rb").read()
+    for knob in (b"RWR_SPMM_SLICE_PROBE", b"RWR_BLOCKED_DBG", b"RWR_SMALL_DBG", b"RWR_SPMV_BLOCKED", b"RWR_SPMM_WIDE",
+                 b"k_spmm_slice_probe", b"k_spmm_vf_wide", b"k_spmv_blocked", b"k_spmv_vector", b"k_restart_final"):
+        assert knob not in blob, knob
+    # every environment variable the library reads is a documented selector between CORRECT code paths (DESIGN.md 3.7)
+    knobs = set(re.findall(rb"RWR_[A-Z0-9_]+", blob))
+    design = open(os.path.join(ROOT, "DESIGN.md"), "rb").read()
+    status = {b"RWR_OK", b"RWR_E_INVALID", b"RWR_E_RANGE", b"RWR_E_NOMEM", b"RWR_E_HIP", b"RWR_E_NO_DEVICE", b"RWR_E_UNSUPPORTED",
+              b"RWR_E_STATE", b"RWR_HIP", b"RWR_TRY", b"RWR_MODE_EXACT"}
+    assert all(k in design for k in knobs - status), sorted(k for k in knobs - status if k not in design)
+
+
+def test_csharp_shim_structs_match_the_ctypes_mirror():
+    """The C# shim cannot be compiled in this image (no dotnet / mono), so its P/Invoke structs are checked as text: the
+    [StructLayout(Sequential)] fields of RwrOpts in csharp/.../Native.cs, laid out with natural alignment, must have the
+    names, order, sizes and offsets of the ctypes mirror (which test_struct_layouts_match_header ties to rwr.h), and the
+    struct_size the shim passes must be the struct's size."""
+    L = _lib()
+    src = open(os.path.join(ROOT, "csharp", "Recommenders", "RWRBased", "Native.cs")).read()
+    body = re.search(r"struct RwrOpts\s*\{(.*?)\}", src, re.S).group(1)
+    fields, off = [], 0
+    for typ, names in re.findall(r"public\s+(int|long|double|float|byte)\s+([^;]+);", body):
+        size = {"int": 4, "long": 8, "double": 8, "float": 4, "byte": 1}[typ]
+        for name in [x.strip() for x in names.split(",")]:
+            off = (off + size - 1) // size * size
+            fields.append((name, off, size))
+            off += size
+    total = (off + 7) // 8 * 8
+    mirror = [(name, getattr(L.rwr_opts, name).offset, getattr(L.rwr_opts, name).size) for name, _ in L.rwr_opts._fields_]
+    assert fields == mirror, (fields, mirror)
+    assert total == C.sizeof(L.rwr_opts) == 40
+    graph_cs = open(os.path.join(ROOT, "csharp", "Recommenders", "RWRBased", "Graph.cs")).read()
+    assert re.search(r"struct_size\s*=\s*40\b", graph_cs)

@@ -36,8 +36,12 @@ def test_single_rank_needs_no_launcher():
 def test_under_torchrun_the_process_is_a_rank():
     """Launched by torch.distributed.run (WORLD_SIZE set) the script must NOT start a second launcher."""
     env = {k: v for k, v in os.environ.items()}
+    import socket
+    with socket.socket() as sk:                     # a free rendezvous port (a fixed one collides with parallel test runs)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run",
                         "--config", "tiny"], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -72,16 +72,14 @@ def test_full_size_properties(big):
     assert (bits(r) == bits(m.rank)).all()
 
 
-def test_full_size_fast_mode_within_tolerance(big):
+def test_removed_fast_mode_is_rejected(big):
+    """Mode 1 (FAST until ABI 3: re-associated sums, no ranking guarantee) is gone: rwr_graph_create refuses it."""
     amd, synth, g, flat, G = big
-    Gf = amd.Graph.from_flat(**flat, mode="fast")
-    Gf.buildGraph()
-    seeds = synth.seeds_for(g["users"], 64, 0, 64)
-    ids, sc, cnt = amd.Recommender(G).RecommendationBatch(seeds, 0.15, 10, 100)
-    idf, scf, cntf = amd.Recommender(Gf).RecommendationBatch(seeds, 0.15, 10, 100)
-    assert (ids == idf).all() and (cnt == cntf).all()           # top-k lists identical
-    assert np.abs(sc - scf).max() <= 1e-6                       # north_star: rank scores within 1e-6
-    Gf.close()
+    from recommendersystems_amd import _lib
+    Gf = amd.Graph.from_flat(**flat)
+    Gf._opts.mode = 1
+    with pytest.raises(Exception):
+        Gf.buildGraph()
 
 
 def test_monotone_id_relabelling_keeps_scores(big):

@@ -1,6 +1,6 @@
 """Parity tests proper: the HIP path, called through the C-ABI (ctypes), against the oracle
-on the same seeded inputs.  EXACT mode must be bitwise; FAST mode within 1e-6 with identical
-top-k lists."""
+on the same seeded inputs.  Every rank value and score must be bitwise the oracle's, every ranked
+list identical (north_star asks for identical top-k lists and scores within 1e-6: bitwise implies both)."""
 import ctypes as C
 
 import numpy as np
@@ -102,29 +102,24 @@ def test_small_exact_bitwise_vs_literal_python(amd, case, tile_seeds, seed_row_k
 
 
 @pytest.mark.parametrize("case", MEDIUM, ids=lambda c: f"g{c['seed']}")
-@pytest.mark.parametrize("mode", ["exact", "fast"])
-def test_medium_batch_vs_c_oracle(amd, case, mode):
+def test_medium_batch_vs_c_oracle(amd, case):
     g = gg.random_graph(**case)
     F = FlatGraph(**g)
-    G = dev_graph(amd, g, mode=mode)
+    G = dev_graph(amd, g)
     rec = amd.Recommender(G)
     K = 70
     seeds = np.linspace(0, case["n_users"] - 1, K).astype(np.int32)
     ids, sc, cnt = rec.RecommendationBatch(seeds, 0.15, 10, 25)
     oi, os_, oc = F.recommend_batch(seeds, 0.15, 10, 25)
     assert (cnt == oc).all()
-    assert (ids == oi).all()                       # top-k id lists identical in both modes
-    if mode == "exact":
-        assert (bits(sc) == bits(os_)).all()
-    else:
-        assert np.abs(sc - os_).max() <= 1e-6      # north_star: rank scores within 1e-6
+    assert (ids == oi).all()                       # top-k id lists identical
+    assert (bits(sc) == bits(os_)).all()           # (north_star asks for 1e-6; the engine is bitwise)
     # single-seed full list == batch prefix
     full = rec.Recommendation(int(seeds[5]), 0.15, 10)
     assert [r[0] for r in full[:cnt[5]]] == ids[5, :cnt[5]].tolist()
     fi, fs = F.recommend(int(seeds[5]), 0.15, 10)
     assert [r[0] for r in full] == fi.tolist()
-    if mode == "exact":
-        assert (bits([r[1] for r in full]) == bits(fs)).all()
+    assert (bits([r[1] for r in full]) == bits(fs)).all()
 
 
 def test_properties_exact(amd):
@@ -476,27 +471,6 @@ def test_seed_row_binade_scan_bitwise(amd, tile_seeds):
     assert 0 < outs["scan"] < 0.5 * nblocks * len(seeds) * 7, outs
 
 
-@pytest.mark.parametrize("case", SMALL[:2] + MEDIUM, ids=lambda c: f"g{c['seed']}")
-def test_single_seed_fast_mode_vector_spmv(amd, case):
-    """K = 1 in FAST mode runs the vector-CSR SpMV (lanes share a row, shuffle reduction): scores within 1e-6,
-    ranked ids identical, structural ties intact."""
-    g = gg.random_graph(**case)
-    F = FlatGraph(**g)
-    G = dev_graph(amd, g, mode="fast")
-    rec = amd.Recommender(G)
-    for seed in (0, case["n_users"] // 2, case["n_users"] - 1):
-        ids, sc = F.recommend(seed, 0.15, 10)
-        got = rec.Recommendation(seed, 0.15, 10)
-        assert len(got) == len(ids)
-        assert np.abs(np.array([r[1] for r in got]) - sc).max() <= 1e-6
-        # positions may only differ inside groups of (near-)equal scores; the top of the list must match exactly
-        assert [r[0] for r in got[:10]] == ids[:10].tolist()
-        m = amd.Model(G, po.widen_float(0.15), seed)
-        m.run(10)
-        r, _ = F.model_run(po.widen_float(0.15), seed, 0, 10)
-        assert np.abs(m.rank - r).max() <= 1e-6 and abs(m.rank.sum() - F.n) < 1e-9 * F.n
-
-
 def test_dangling_seeds_in_a_batch(amd):
     """Seeds without explicit out-links are answered without iterating (rank = n at the seed, 0 elsewhere, for any T):
     users with no links, users whose links are all UNDEFINED, and a dangling ITEM seed (which leads its own list)."""
@@ -525,10 +499,9 @@ def test_dangling_seeds_in_a_batch(amd):
     assert (cnt == oc).all() and (ids == oi).all() and (bits(sc) == bits(os_)).all()
 
 
-@pytest.mark.parametrize("mode", ["exact", "fast"])
-def test_hub_nodes_long_rows(amd, mode):
+def test_hub_nodes_long_rows(amd):
     """One item liked by every user and one user who likes every item: in-lists of 20 000 / 3 000 entries (long
-    sequential rows, workgroup-per-row bin of the K = 1 vector SpMV, a seed with thousands of in-links for the chain)."""
+    sequential rows, the hub-row reduction of the K = 1 SpMV, a seed with thousands of in-links for the chain)."""
     U, I = 20000, 3000
     rng = np.random.default_rng(12)
     lists = {i: [] for i in range(U + I)}
@@ -546,21 +519,18 @@ def test_hub_nodes_long_rows(amd, mode):
     node_type = np.array([gg.NODE_USER] * U + [gg.NODE_ITEM] * I, dtype=np.uint8)
     g = gg._from_lists(node_id, node_type, lists)
     F = FlatGraph(**g)
-    G = dev_graph(amd, g, mode=mode)
+    G = dev_graph(amd, g)
     rec = amd.Recommender(G)
     seeds = np.array([7, 0, 19999, 1234] + list(range(100, 128)), dtype=np.int32)
     ids, sc, cnt = rec.RecommendationBatch(seeds, 0.15, 10, 50)
     oi, os_, oc = F.recommend_batch(seeds, 0.15, 10, 50)
     assert (cnt == oc).all() and (ids == oi).all()
-    if mode == "exact":
-        assert (bits(sc) == bits(os_)).all()
-    else:
-        assert np.abs(sc - os_).max() <= 1e-6
+    assert (bits(sc) == bits(os_)).all()
     assert rec.Recommendation(7, 0.15, 10, 50) == []   # user 7 likes every item: nothing left to recommend
-    single = rec.Recommendation(1234, 0.15, 10, 50)    # K = 1 path (fast: vector SpMV with the long-row bin)
+    single = rec.Recommendation(1234, 0.15, 10, 50)    # K = 1 path
     si, ss = F.recommend(1234, 0.15, 10, 50)
     assert [r[0] for r in single] == si.tolist() and len(si) == 50
-    assert np.abs(np.array([r[1] for r in single]) - ss).max() <= (0 if mode == "exact" else 1e-6)
+    assert (bits([r[1] for r in single]) == bits(ss)).all()
 
 
 def _same_results(amd, G, F, seeds, T=6, top_n=15):
