@@ -424,6 +424,10 @@ int32_t graph_update_links(rwr_graph *g, int64_t count, const int64_t *idx, cons
 // Graph.buildGraph + transpose + processing orders, from the device-resident raw lists
 static int32_t graph_derive(rwr_graph *g, bool first)
 {
+    g->sw_state = 0;   // the sweep form of the single-seed SpMV re-decides (and rebuilds its tables) on first use
+    g->sw_meta.release();
+    g->sw_order.release();
+    g->sw_ent.release();
     g->part_G = 0;   // a row-partitioned run sized for the previous matrix is over: rwr_part_step asks for a new rwr_part_begin
 
     const int32_t n = g->n;

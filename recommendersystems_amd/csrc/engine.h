@@ -64,6 +64,14 @@ struct rwr_graph {
     rwr::DevBuf<int32_t> item_order;  // ITEM rows by id descending
     rwr::DevBuf<int32_t> item_rows;   // ITEM rows by row index ascending
 
+    // single-seed SpMV of value-free graphs as a source-block sweep with z staged through LDS (sweep.hip): 0 = not decided
+    // yet, 1 = tables built, -1 = this graph does not qualify; re-decided after every (re)build
+    int32_t sw_state = 0, sw_B = 0, sw_BN = 0, sw_K = 0, sw_nwg = 0, sw_wpg = 0, sw_hub0 = 0;
+    int64_t sw_words = 0;             // 64-bit words of the entry stream (4 block-local 16-bit indices each)
+    rwr::DevBuf<int32_t> sw_order;    // rows in sweep order (row_order_x without its hub rows)
+    rwr::DevBuf<uint4> sw_meta;       // [wave][block]: first word-row of the chunk, piece lengths of the wave's slots
+    rwr::DevBuf<uint2> sw_ent;        // the matrix in sweep order
+
     // batch workspace (lazily sized)
     rwr::DevBuf<double> X, Y;         // rank matrices [tile][n][G]
     rwr::DevBuf<int32_t> sm_tab;      // small.hip: places of the seed row's addends (per call)
@@ -150,6 +158,11 @@ int32_t model_deliver(rwr_graph *g, int32_t seed, double d, const double *rank_i
 void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *seeds, double c1, int skip,
                        const uint32_t *act, uint32_t *nz_out, hipStream_t s, const double *zin = nullptr,
                        double *zout = nullptr, bool hub_scan = false);
+// sweep.hip: single-seed SpMV of value-free graphs, z staged through LDS source block by source block (bitwise the same sums)
+int32_t sweep_prepare(rwr_graph *g);
+bool sweep_ready(const rwr_graph *g);
+void launch_sweep(rwr_graph *g, const double *zin, double *Y, double *zout, const int32_t *seeds, int skip, double c1,
+                  hipStream_t s);
 // small.hip: ego-network-sized graphs, one single-seed Recommendation as ONE kernel launch (bitwise the EXACT path's result)
 bool small_path_ok(const rwr_graph *g);
 bool small_path_seed_ok(const rwr_graph *g, int32_t seed);

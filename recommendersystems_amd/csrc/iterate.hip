@@ -844,6 +844,7 @@ struct GroupIter {
         scan = c1 >= 0.0 && c1 <= 1.0 && g->nonneg && ranks_nonneg &&
                (chain_kind == 2 || (chain_kind == 1 && (double)tg * G * per_seed < scan_work));
         if (scan) RWR_TRY(chain_scan_prepare(g, G, tg, d_seeds, s));
+        if (Zc && G == 1 && tg == 1 && addends_nonneg) RWR_TRY(sweep_prepare(g));   // single seed: the source-block sweep (sweep.hip)
         // (the simple one-lane reference kernel of the seed row walks the weighted in-lists itself)
         if (Zc && chain_kind == 0 && !scan) RWR_TRY(ensure_in_w(g));
         return RWR_OK;

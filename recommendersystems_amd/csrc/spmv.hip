@@ -247,10 +247,10 @@ __global__ __launch_bounds__(256) void k_spmv_exact_binned(int nb0, int nb1, int
 // every few entries while it is small), the rest in passes of 1024 -- lane l fetches ITS 16 consecutive entries (64
 // contiguous bytes of indices), gathers their values, and wave_fold_exact composes the 64 runs.  One wave per row; the
 // kernel runs beside k_spmv_exact_binned on a stream of its own.
-constexpr int HS_R = 16;
+constexpr int HS_R = 8;    // (8, not 16: at 16 the kernel needs 244 registers per lane and cannot share a SIMD with the sweep kernel's waves)
 constexpr int HS_PASS = WAVE * HS_R;
 template <bool VF>
-__global__ __launch_bounds__(WAVE) void k_spmv_exact_hub(int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
+__global__ __launch_bounds__(WAVE, 3) void k_spmv_exact_hub(int32_t r0, int32_t r1, const int64_t *__restrict__ in_ptr,
                                                          const int32_t *__restrict__ in_src,
                                                          const double *__restrict__ in_w,
                                                          const int32_t *__restrict__ row_order,
@@ -262,6 +262,9 @@ __global__ __launch_bounds__(WAVE) void k_spmv_exact_hub(int32_t r0, int32_t r1,
     const int lane = threadIdx.x;
     const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
     uint32_t *nz_out = nullptr;
+    // a hub row is one long dependent chain: beside the sweep kernel (sweep.hip), whose waves are many and mostly waiting at
+    // barriers, this wave should win the SIMD's issue arbitration
+    __builtin_amdgcn_s_setprio(3);
     for (int32_t r = r0 + blockIdx.x; r < r1; r += gridDim.x) {
         const int32_t j = row_order[r];
         if (j == my_seed) continue;
@@ -299,15 +302,26 @@ __global__ __launch_bounds__(WAVE) void k_spmv_exact_hub(int32_t r0, int32_t r1,
             }
             p = ea;
         }
-        // the rest in passes of HS_PASS: every lane's 16 consecutive entries, then the exact parallel fold
-        for (; p < e; p += HS_PASS) {
-            const int64_t left = e - p;
-            const int cnt = left < HS_PASS ? (int)left : HS_PASS;
-            const int64_t q0 = p + (int64_t)lane * HS_R;
-            int32_t idx[HS_R];
-            double v[HS_R];
+        // the rest in passes of HS_PASS: every lane's 16 consecutive entries, then the exact parallel fold.  Three passes are
+        // in flight: the indices of pass k+2 and the gathers of pass k+1 are requested before pass k is folded, so the fold
+        // (the only sequential part: it needs the running sum) never waits for memory -- the longest row of the
+        // MovieLens-shaped graph (29 000 in-links) bounds the whole step, and it was spending two memory round trips per pass.
+        auto load_idx = [&](int64_t pp, int32_t (&idx)[HS_R]) {
+            const int64_t left = e - pp;
+            const int64_t q0 = pp + (int64_t)lane * HS_R;
+            if (left >= HS_PASS) {
 #pragma unroll
-            for (int u = 0; u < HS_R; ++u) idx[u] = (lane * HS_R + u < cnt) ? in_src[q0 + u] : -1;
+                for (int u = 0; u < HS_R; u += 4) {
+                    const v4i_u t = *reinterpret_cast<const v4i_u *>(in_src + q0 + u);
+                    idx[u] = t.x; idx[u + 1] = t.y; idx[u + 2] = t.z; idx[u + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < HS_R; ++u) idx[u] = (lane * HS_R + u < (int)left) ? in_src[q0 + u] : -1;
+            }
+        };
+        auto gather = [&](int64_t pp, const int32_t (&idx)[HS_R], double (&v)[HS_R]) {
+            const int64_t q0 = pp + (int64_t)lane * HS_R;
 #pragma unroll
             for (int u = 0; u < HS_R; ++u) {
                 v[u] = 0.0;
@@ -316,7 +330,24 @@ __global__ __launch_bounds__(WAVE) void k_spmv_exact_hub(int32_t r0, int32_t r1,
                     else { const double rw = c1 * x[idx[u]]; v[u] = rw * in_w[q0 + u]; }      // Model.cs:84,87
                 }
             }
-            acc = wave_fold_exact<HS_R>(acc, v, lane);                                        // list order, bit for bit
+        };
+        int32_t ia[HS_R], ib[HS_R];
+        double va[HS_R], vb[HS_R];
+        if (p < e) {
+            load_idx(p, ia);
+            gather(p, ia, va);
+            if (p + HS_PASS < e) load_idx(p + HS_PASS, ib);
+        }
+        while (p < e) {
+            if (p + HS_PASS < e) gather(p + HS_PASS, ib, vb);
+            if (p + 2 * HS_PASS < e) load_idx(p + 2 * HS_PASS, ia);
+            acc = wave_fold_exact<HS_R>(acc, va, lane);                                       // list order, bit for bit
+            p += HS_PASS;
+            if (p >= e) break;
+            if (p + HS_PASS < e) gather(p + HS_PASS, ia, va);
+            if (p + 2 * HS_PASS < e) load_idx(p + 2 * HS_PASS, ib);
+            acc = wave_fold_exact<HS_R>(acc, vb, lane);
+            p += HS_PASS;
         }
         if (lane == 0) RWR_SPMV_STORE(j, acc)
     }
@@ -337,18 +368,23 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
     const int phases = phases_env >= 0 ? phases_env : (g->n >= spmv_big_n() ? 1 : 0);
     const bool vf = zin != nullptr;
     const double *gs = vf ? zin : X;       // gather source
+    // dense step of a value-free graph whose tables are built: the source-block sweep (sweep.hip) for every row below
+    // hub_t in-links, the hub rows beside it as below
+    const bool sweep = vf && hub_scan && !act && !nz_out && sweep_ready(g) && g->stream3 && s != g->stream3;
     // hub rows (>= hub_t in-links, first in the in-degree order): exact parallel reduction, one wave per row, on a stream of
     // its own beside the binned kernel (dense steps only, and only when every addend is known to be >= 0)
     static const int hub_env = [] { const char *e = getenv("RWR_HUB_SCAN"); return e ? atoi(e) : 1; }();
-    const bool hubs = hub_scan && hub_env && by_degree && !act && !nz_out && g->stream3 && s != g->stream3;
+    const bool hubs = sweep || (hub_scan && hub_env && by_degree && !act && !nz_out && g->stream3 && s != g->stream3);
     bool forked = false;
+    auto fork = [&]() {
+        if (forked) return;
+        (void)hipEventRecord(g->ev_h0, s);
+        (void)hipStreamWaitEvent(g->stream3, g->ev_h0, 0);
+        forked = true;
+    };
     auto launch_hubs = [&](const int32_t *order, int32_t ra, int32_t nh) {
         if (nh <= 0) return;
-        if (!forked) {
-            (void)hipEventRecord(g->ev_h0, s);
-            (void)hipStreamWaitEvent(g->stream3, g->ev_h0, 0);
-            forked = true;
-        }
+        fork();
         const unsigned grid = (unsigned)(nh < 4096 ? nh : 4096);
         static const int prefix = [] { const char *e = getenv("RWR_HUB_PREFIX"); return e ? atoi(e) : 256; }();
         if (vf)
@@ -380,7 +416,22 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
             hipLaunchKernelGGL(k_spmv_exact_binned<false>, dim3((unsigned)(nb0 + nb1 + nb2 + nb3)), dim3(256), 0, s, nb0, nb1, nb2, nb3, ra, b0,
                                b1, b2, rend, g->in_ptr.p, g->in_src.p, g->in_w.p, order, gs, Y, seeds, c1, skip, act, nz_out, g->w_src.p, zout);
     };
-    if (by_degree && phases) {
+    if (sweep) {
+#ifdef RWR_EXPERIMENTS
+        // timing probes of the experiments build only (results are WRONG with either set): one of the two kernels alone
+        static const int x_only = [] { const char *e = getenv("RWR_X_SWEEP_ONLY"); return e ? atoi(e) : 0; }();
+        if (x_only != 1 && g->x_hub[0] + g->x_hub[1] > 0) fork();
+        if (x_only != 2) launch_sweep(g, zin, Y, zout, seeds, skip, c1, s);
+        if (x_only != 1) { launch_hubs(g->row_order_x.p, 0, g->x_hub[0]); launch_hubs(g->row_order_x.p, g->x_rows[0], g->x_hub[1]); }
+#else
+        // (the sweep first: its one workgroup per CU needs 128 KB of LDS and 16 wave slots at once, which a CU already full
+        //  of hub-row waves could not offer until they retire; the hub kernel then fills what is left beside it)
+        if (g->x_hub[0] + g->x_hub[1] > 0) fork();          // (the fork point lies BEFORE the sweep in the main stream)
+        launch_sweep(g, zin, Y, zout, seeds, skip, c1, s);
+        launch_hubs(g->row_order_x.p, 0, g->x_hub[0]);
+        launch_hubs(g->row_order_x.p, g->x_rows[0], g->x_hub[1]);
+#endif
+    } else if (by_degree && phases) {
         launch(g->row_order_x.p, 0, g->x_rows[0], g->x_bins[0], g->x_hub[0]);
         launch(g->row_order_x.p, g->x_rows[0], g->x_rows[1], g->x_bins[1], g->x_hub[1]);
     } else {

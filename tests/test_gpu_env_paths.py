@@ -7,7 +7,10 @@ process (tests/env_child.py) and compared with the C restatement of the referenc
   seed on the list-order kernels, 32-seed tiles -- which the default threshold only selects from 2 M nodes on (the 100 M-like
   headline configuration): RWR_BIG_N lowers the threshold so that oracle-sized graphs run them;
 * the general single-seed path on ego-network-sized graphs (RWR_SMALL=0), which by default take the one-launch kernel of
-  small.hip -- both must equal the oracle bit for bit."""
+  small.hip -- both must equal the oracle bit for bit;
+* the source-block sweep of the single-seed SpMV (sweep.hip), which by default serves graphs of >= 50 000 nodes only:
+  RWR_SWEEP_MIN_N=0 sends the oracle-sized graphs through it, RWR_SWEEP_BN shrinks the LDS block so that they span many
+  blocks, RWR_HUB_T lowers the hub-row threshold so that hub kernel and sweep share the rows of one step."""
 import os
 import subprocess
 import sys
@@ -33,13 +36,14 @@ def run_child(env_extra):
     {"RWR_VALUE_FREE": "0"},
     {"RWR_BIG_N": "100", "RWR_SPMV_PHASES": "1", "RWR_ACT_ITERS": "3"},
     {"RWR_BIG_N": "100", "RWR_VALUE_FREE": "0"},
-    {"RWR_SPMV_BLOCKED": "1"},
+    {"RWR_SWEEP_MIN_N": "0", "RWR_SMALL": "0"},
+    {"RWR_SWEEP_MIN_N": "0", "RWR_SMALL": "0", "RWR_SWEEP_BN": "512"},
+    {"RWR_SWEEP_MIN_N": "0", "RWR_SMALL": "0", "RWR_SWEEP_BN": "128", "RWR_HUB_T": "96"},
+    {"RWR_SWEEP": "0"},
     {"RWR_HUB_SCAN": "0"},
     {"RWR_SMALL": "0"},
     {"RWR_SMALL": "0", "RWR_VALUE_FREE": "0"},
     {"RWR_SPMM": "0"},
-    {"RWR_SPMM_WIDE": "1"},
-    {"RWR_SPMM_WIDE": "1", "RWR_BIG_N": "100"},
     {"RWR_CHAIN": "0"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_env_selected_paths_match_the_oracle(env):

@@ -1,4 +1,4 @@
-"""Event-timed single-seed SpMV (dense steps) on one configuration: `python tools/k1_time.py C3 [exact|fast]`.
+"""Event-timed single-seed SpMV (dense steps) on one configuration: `python tools/k1_time.py C3`.
 Prints one line: per-launch time of the dense SpMV steps and the wall time of the call.  Experiment knobs come from the
 environment (read once per process by librwr), so A/B runs are separate invocations."""
 import os
@@ -6,11 +6,13 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from recommendersystems_amd import synth                                  # noqa: E402
+from recommendersystems_amd import synth, _lib                            # noqa: E402
+if os.environ.get("RWR_TOOLS_EXP_LIB"):        # the experiments build (make -C recommendersystems_amd/csrc exp): timing probes
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "librwr_exp.so")
 from recommendersystems_amd.rwr_based import Graph, Recommender           # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
-mode = sys.argv[2] if len(sys.argv) > 2 else "exact"
+mode = "exact"
 no, U, I, E, K = synth.CONFIGS[cfg]
 g = synth.bipartite(no, U, I, E)
 flat = {k: g[k] for k in ("node_id", "node_type", "rowptr", "dst", "etype", "w")}
