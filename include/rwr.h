@@ -198,6 +198,14 @@ int32_t rwr_recommend(rwr_graph *g, int32_t seed, float d, int32_t n_iter, int32
 int32_t rwr_recommend_eval(rwr_graph *g, int32_t seed, float d, int32_t n_iter, const int64_t *test_ids,
                            int64_t n_test, int64_t *n_hits, double *sum_precision, int64_t *list_len);
 
+/* The same for K seeds of one graph, each with its own test set: test set k = test_ids[test_ptr[k] .. test_ptr[k+1])
+ * (CSR form, test_ptr has K + 1 entries).  n_hits / sum_precision / list_len (optional) have K entries; entry k is
+ * exactly what rwr_recommend_eval(seeds[k], ..., test set k) returns.  The K full ranked lists are produced by the
+ * batched iteration and evaluated where they lie (one workgroup per seed); nothing but 16 bytes per seed comes back. */
+int32_t rwr_recommend_eval_batch(rwr_graph *g, const int32_t *seeds, int32_t K, float d, int32_t n_iter,
+                                 const int64_t *test_ptr, const int64_t *test_ids, int64_t *n_hits,
+                                 double *sum_precision, int64_t *list_len);
+
 /* Batch entry (an addition: the reference creates a fresh Model per call, Recommender.cs:16,
  * so seeds are independent and batching is semantically free).  top_n must be >= 1.
  * ids/scores are K x top_n row-major; counts[k] = entries valid in row k (the rest of the

@@ -19,7 +19,7 @@ RWR_RUN_ITERATIONS, RWR_RUN_THRESHOLD, RWR_RUN_DEFAULT_THRESHOLD = 0, 1, 2
 EXPORTS = [
     "rwr_version", "rwr_device_count", "rwr_last_error",
     "rwr_graph_create", "rwr_graph_update_links", "rwr_graph_destroy", "rwr_graph_size", "rwr_graph_get_normalized",
-    "rwr_recommend", "rwr_recommend_eval", "rwr_recommend_batch", "rwr_model_run", "rwr_model_deliver",
+    "rwr_recommend", "rwr_recommend_eval", "rwr_recommend_eval_batch", "rwr_recommend_batch", "rwr_model_run", "rwr_model_deliver",
     "rwr_part_begin", "rwr_part_step", "rwr_part_local_step", "rwr_part_finish_step", "rwr_part_rank",
     "rwr_get_stats", "rwr_reset_stats",
 ]
@@ -81,6 +81,9 @@ def load():
     lib.rwr_recommend_eval.restype = C.c_int32
     lib.rwr_recommend_eval.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, p(C.c_int64), C.c_int64,
                                        p(C.c_int64), p(C.c_double), p(C.c_int64)]
+    lib.rwr_recommend_eval_batch.restype = C.c_int32
+    lib.rwr_recommend_eval_batch.argtypes = [C.c_void_p, p(C.c_int32), C.c_int32, C.c_float, C.c_int32, p(C.c_int64),
+                                             p(C.c_int64), p(C.c_int64), p(C.c_double), p(C.c_int64)]
     lib.rwr_recommend_batch.restype = C.c_int32
     lib.rwr_recommend_batch.argtypes = [C.c_void_p, p(C.c_int32), C.c_int32, C.c_float, C.c_int32, C.c_int32,
                                         p(C.c_int64), p(C.c_double), p(C.c_int32)]

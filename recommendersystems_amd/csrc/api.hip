@@ -118,6 +118,78 @@ static void kit_give(HandleKit &k)
     kit_destroy(k);
 }
 
+// ---------------------------------------------------------------------------------------------- device-memory cache
+// (common.h: DevBuf).  Blocks of 512 B ... 32 MB in power-of-two sizes, kept per device when handed back, up to
+// POOL_CAP bytes per device; larger requests go straight to hipMalloc / hipFree.
+namespace {
+constexpr size_t POOL_MIN = 512, POOL_MAX = 32ull << 20, POOL_CAP = 2ull << 30;
+constexpr int POOL_DEVICES = 16, POOL_CLASSES = 17;                 // 512 B << 16 = 32 MB
+struct PoolDev { std::vector<void *> free_blocks[POOL_CLASSES]; size_t cached = 0; };
+std::mutex g_pool_mutex;
+PoolDev g_pool[POOL_DEVICES];
+inline int pool_class(size_t bytes, size_t *size)
+{
+    size_t sz = POOL_MIN;
+    int c = 0;
+    while (sz < bytes) { sz <<= 1; ++c; }
+    *size = sz;
+    return c;
+}
+}  // namespace
+
+void *pool_alloc(size_t bytes, size_t *got)
+{
+    void *p = nullptr;
+    if (bytes > POOL_MAX) {
+        *got = bytes;
+        return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr;
+    }
+    size_t size = 0;
+    const int c = pool_class(bytes, &size);
+    *got = size;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < POOL_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        auto &fl = g_pool[dev].free_blocks[c];
+        if (!fl.empty()) {
+            p = fl.back();
+            fl.pop_back();
+            g_pool[dev].cached -= size;
+            return p;
+        }
+    }
+    if (hipMalloc(&p, size) == hipSuccess) return p;
+    // out of memory with blocks parked in the cache: give them back to the driver and try once more
+    (void)hipGetLastError();
+    std::vector<void *> drop;
+    if (dev >= 0 && dev < POOL_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        for (auto &fl : g_pool[dev].free_blocks) { drop.insert(drop.end(), fl.begin(), fl.end()); fl.clear(); }
+        g_pool[dev].cached = 0;
+    }
+    for (void *q : drop) (void)hipFree(q);
+    return hipMalloc(&p, size) == hipSuccess ? p : nullptr;
+}
+
+void pool_free(void *p, size_t got)
+{
+    if (!p) return;
+    int dev = -1;
+    if (got <= POOL_MAX && got >= POOL_MIN && (got & (got - 1)) == 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 &&
+        dev < POOL_DEVICES) {
+        // (the block belongs to the current device: every entry point binds the handle's device before it touches memory)
+        size_t size = 0;
+        const int c = pool_class(got, &size);
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        if (g_pool[dev].cached + size <= POOL_CAP) {
+            g_pool[dev].free_blocks[c].push_back(p);
+            g_pool[dev].cached += size;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
 }  // namespace rwr
 
 using namespace rwr;
@@ -370,6 +442,53 @@ int32_t rwr_recommend_eval(rwr_graph *g, int32_t seed, float d, int32_t n_iter, 
     ts.erase(std::unique(ts.begin(), ts.end()), ts.end());     // HashSet<long>
     RWR_TRY(eval_ranked(g, cnt, ts.data(), (int64_t)ts.size(), n_hits, sum_precision));
     if (list_len) *list_len = cnt;
+    return RWR_OK;
+}
+
+int32_t rwr_recommend_eval_batch(rwr_graph *g, const int32_t *seeds, int32_t K, float d, int32_t n_iter,
+                                 const int64_t *test_ptr, const int64_t *test_ids, int64_t *n_hits, double *sum_precision,
+                                 int64_t *list_len)
+{
+    g_err[0] = 0;
+    if (!g || !seeds || K < 0 || !test_ptr || !n_hits || !sum_precision) {
+        set_error("rwr_recommend_eval_batch: bad argument");
+        return RWR_E_INVALID;
+    }
+    for (int32_t k = 0; k < K; ++k) {
+        if (seeds[k] < 0 || seeds[k] >= g->n) { set_error("seed %d (batch position %d) is outside [0, %d)", seeds[k], k, g->n); return RWR_E_RANGE; }
+        if (test_ptr[k + 1] < test_ptr[k] || test_ptr[k + 1] - test_ptr[k] > 0x7FFFFFFF) {
+            set_error("rwr_recommend_eval_batch: test_ptr must be non-decreasing (position %d)", k);
+            return RWR_E_INVALID;
+        }
+    }
+    if (K > 0 && test_ptr[K] > test_ptr[0] && !test_ids) { set_error("rwr_recommend_eval_batch: test_ids is NULL"); return RWR_E_INVALID; }
+    if (n_iter < 0) n_iter = 0;
+    RWR_BIND(g);
+    for (int32_t k = 0; k < K; ++k) { n_hits[k] = 0; sum_precision[k] = 0.0; if (list_len) list_len[k] = 0; }
+    const int32_t width = g->n_items;
+    if (width == 0 || K == 0) return RWR_OK;
+    // HashSet<long> semantics per test set (Experiment.cs:124): sorted, duplicates dropped; offsets rebuilt
+    std::vector<int64_t> ts, tp((size_t)K + 1, 0);
+    ts.reserve((size_t)(test_ptr[K] - test_ptr[0]));
+    for (int32_t k = 0; k < K; ++k) {
+        const size_t at = ts.size();
+        ts.insert(ts.end(), test_ids + test_ptr[k], test_ids + test_ptr[k + 1]);
+        std::sort(ts.begin() + at, ts.end());
+        ts.erase(std::unique(ts.begin() + at, ts.end()), ts.end());
+        tp[(size_t)k + 1] = (int64_t)ts.size();
+    }
+    // the full ranked lists stay on the device, `chunk` seeds at a time (16 bytes per candidate and seed)
+    const int64_t per_seed = (int64_t)width * 16;
+    int32_t chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(K, (1ll << 30) / std::max<int64_t>(per_seed, 1)));
+    std::vector<int32_t> cnt((size_t)K);
+    for (int32_t k0 = 0; k0 < K; k0 += chunk) {
+        const int32_t kc = std::min(chunk, K - k0);
+        RWR_TRY(recommend_batch(g, seeds + k0, kc, (double)d, n_iter, width, nullptr, nullptr, cnt.data() + k0, width));
+        std::vector<int64_t> tpc((size_t)kc + 1);
+        for (int32_t q = 0; q <= kc; ++q) tpc[q] = tp[(size_t)k0 + q] - tp[k0];
+        RWR_TRY(eval_ranked_batch(g, kc, width, tpc.data(), ts.data() + tp[k0], n_hits + k0, sum_precision + k0));
+    }
+    if (list_len) for (int32_t k = 0; k < K; ++k) list_len[k] = cnt[k];
     return RWR_OK;
 }
 

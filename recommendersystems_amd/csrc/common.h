@@ -47,15 +47,29 @@ __host__ __device__ static inline uint64_t i64_orderable(int64_t x)
 }
 
 // ------------------------------------------------------------------ device buffers
+// Device memory of up to 32 MB comes from a per-device cache of power-of-two blocks (api.hip): the reference's workload is
+// thousands of ego-network graphs, one Graph per fold from up to ten host threads (Program.cs:11, Experiment.cs:69-105),
+// and every hipMalloc / hipFree of the ~40 buffers of a handle is a device-wide synchronisation point that serialises
+// those threads.  A block is handed back only by code that has synchronised the stream(s) it was used on (handle
+// destruction; the end of a call for its scratch buffers), so a recycled block is idle.  *got = bytes actually reserved.
+void *pool_alloc(size_t bytes, size_t *got);
+void pool_free(void *p, size_t got);
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t count = 0;
+    size_t reserved = 0;      // bytes behind p (pool block size)
     int32_t alloc(size_t n_elems)
     {
         release();
         if (n_elems == 0) n_elems = 1;
-        RWR_HIP(hipMalloc((void **)&p, n_elems * sizeof(T)));
+        p = (T *)pool_alloc(n_elems * sizeof(T), &reserved);
+        if (!p) {
+            const hipError_t e = hipGetLastError();
+            rwr::set_error("device allocation of %zu bytes failed: %s", n_elems * sizeof(T), hipGetErrorString(e));
+            return (e == hipErrorOutOfMemory) ? RWR_E_NOMEM : RWR_E_HIP;
+        }
         count = n_elems;
         return RWR_OK;
     }
@@ -66,9 +80,10 @@ struct DevBuf {
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) pool_free(p, reserved);
         p = nullptr;
         count = 0;
+        reserved = 0;
     }
     ~DevBuf() { release(); }
     DevBuf() = default;

@@ -142,6 +142,8 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
                         int64_t *ids, double *scores, int32_t *counts, int64_t row_stride);
 int32_t eval_ranked(rwr_graph *g, int32_t cnt, const int64_t *test_sorted_host, int64_t n_test, int64_t *n_hits,
                     double *sum_precision);
+int32_t eval_ranked_batch(rwr_graph *g, int32_t K, int64_t row_stride, const int64_t *test_ptr_host,
+                          const int64_t *test_sorted_host, int64_t *n_hits, double *sum_precision);
 int32_t part_begin(rwr_graph *g, int32_t lo, int32_t hi, const int32_t *seeds, int32_t K, double d, double *x,
                    int32_t *G_out);
 int32_t part_local_step(rwr_graph *g, const double *x, double *y, double *r);

@@ -1436,7 +1436,11 @@ int32_t part_begin(rwr_graph *g, int32_t lo, int32_t hi, const int32_t *seeds, i
         if (seeds[k] < 0 || seeds[k] >= n) { set_error("seed %d is outside [0, %d)", seeds[k], n); return RWR_E_RANGE; }
     int G = 1;
     while (G < K) G <<= 1;
-    RWR_TRY(ensure_in_w(g));   // (the slab step runs the weighted kernels on the caller's rank matrix)
+    // value-free graphs (every BASELINE configuration): the slab step forms z = ((1-d) x) * w_src for the slab's rows and
+    // the kernels gather z -- 4 instead of 12 matrix bytes per entry, and no in_w (2 GB per rank at 1/8 of the 1 G-like
+    // graph) is ever materialised; other graphs run the weighted kernels on the caller's rank matrix
+    if (g->vf) RWR_TRY(g->Z0.ensure((size_t)(hi - lo > 0 ? hi - lo : 1) * (size_t)G));
+    else RWR_TRY(ensure_in_w(g));
     g->part_lo = lo; g->part_hi = hi; g->part_G = G; g->part_K = K; g->part_c1 = 1 - d;
     g->part_seeds.assign((size_t)G, -1);
     for (int32_t k = 0; k < K; ++k) g->part_seeds[k] = seeds[k];
@@ -1452,6 +1456,29 @@ int32_t part_begin(rwr_graph *g, int32_t lo, int32_t hi, const int32_t *seeds, i
     return RWR_OK;
 }
 
+// y = (1-d) P_slab^T x over all n rows.  Value-free graphs: z of the slab's rows first (the in-lists of the slab graph
+// hold in-slab sources only, so the kernels' gathers z[source * G + k] never leave [lo, hi): the buffer holds just the
+// slab, addressed through a base pointer shifted by lo rows)
+static int32_t part_spmm(rwr_graph *g, const double *x, double *y, hipStream_t s)
+{
+    const int G = g->part_G;
+    const double c1 = g->part_c1;
+    if (g->vf) {
+        const int64_t rows = (int64_t)g->part_hi - g->part_lo;
+        if (rows > 0 && (!g->Z0.p || g->Z0.count < (size_t)rows * G)) { set_error("rwr_part_step: call rwr_part_begin"); return RWR_E_INVALID; }
+        const int64_t elems = rows * G;
+        if (elems > 0)
+            hipLaunchKernelGGL(k_make_z, dim3(cdiv((size_t)elems, 256)), dim3(256), 0, s, elems, G, x + (size_t)g->part_lo * G, g->Z0.p,
+                               g->w_src.p + g->part_lo, c1);
+        const double *zin = g->Z0.p - (size_t)g->part_lo * G;
+        RWR_DISPATCH_G(G, launch_spmm<GG>(g, 1, x, y, g->d_seeds.p, c1, 0, nullptr, nullptr, s, nullptr, zin, nullptr, false));
+    } else {
+        if (!g->in_w.p) { set_error("rwr_part_step: call rwr_part_begin"); return RWR_E_INVALID; }
+        RWR_DISPATCH_G(G, launch_spmm<GG>(g, 1, x, y, g->d_seeds.p, c1, 0, nullptr, nullptr, s));
+    }
+    return RWR_OK;
+}
+
 int32_t part_local_step(rwr_graph *g, const double *x, double *y, double *r)
 {
     const int G = g->part_G;
@@ -1462,7 +1489,7 @@ int32_t part_local_step(rwr_graph *g, const double *x, double *y, double *r)
                                          g->part_hi, g->dangling.p, x, g->d_part.p, c1));
     hipLaunchKernelGGL(k_slab_restart_final, dim3(1), dim3(64), 0, s, G, RP_GRID, g->d_part.p, r);
     // the graph holds only this slab's out-links, so the in-lists contain only in-slab sources
-    RWR_DISPATCH_G(G, launch_spmm<GG>(g, 1, x, y, g->d_seeds.p, c1, 0, nullptr, nullptr, s));
+    RWR_TRY(part_spmm(g, x, y, s));
     RWR_HIP(hipGetLastError());
     RWR_HIP(hipStreamSynchronize(s));
     return RWR_OK;
@@ -1480,7 +1507,7 @@ int32_t part_step(rwr_graph *g, const double *x, double *y, hipStream_t stream)
     RWR_DISPATCH_G(G, hipLaunchKernelGGL(k_slab_restart_partial<GG>, dim3(RP_GRID), dim3(RP_BLOCK), 0, s, g->part_lo,
                                          g->part_hi, g->dangling.p, x, g->d_part.p, c1));
     hipLaunchKernelGGL(k_slab_restart_final, dim3(1), dim3(64), 0, s, G, RP_GRID, g->d_part.p, r);
-    RWR_DISPATCH_G(G, launch_spmm<GG>(g, 1, x, y, g->d_seeds.p, c1, 0, nullptr, nullptr, s));
+    RWR_TRY(part_spmm(g, x, y, s));
     hipLaunchKernelGGL(k_part_add_restart, dim3(1), dim3(64), 0, s, G, y, r, g->d_seeds.p);
     RWR_HIP(hipGetLastError());
     return RWR_OK;

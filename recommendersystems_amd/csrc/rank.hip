@@ -463,10 +463,10 @@ int32_t rank_group_select(rwr_graph *g, int G, int tg, const int32_t *d_slot_k, 
 // (wave ballots), each hit's addend (double)nHits / (i + 1) is stored at its hit number, and a
 // single thread finally adds the addends in rank order (the reference's summation order).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_eval_ranked(const int64_t *__restrict__ ranked, int32_t cnt,
-                                                      const int64_t *__restrict__ test_sorted, int32_t n_test,
-                                                      double *__restrict__ terms, int64_t *__restrict__ out_hits,
-                                                      double *__restrict__ out_sum)
+__device__ __forceinline__ void eval_ranked_body(const int64_t *__restrict__ ranked, int32_t cnt,
+                                                 const int64_t *__restrict__ test_sorted, int32_t n_test,
+                                                 double *__restrict__ terms, int64_t *__restrict__ out_hits,
+                                                 double *__restrict__ out_sum)
 {
     __shared__ int wave_cnt[16];
     __shared__ int base_s;
@@ -513,6 +513,26 @@ __global__ __launch_bounds__(1024) void k_eval_ranked(const int64_t *__restrict_
     }
 }
 
+__global__ __launch_bounds__(1024) void k_eval_ranked(const int64_t *__restrict__ ranked, int32_t cnt,
+                                                      const int64_t *__restrict__ test_sorted, int32_t n_test,
+                                                      double *__restrict__ terms, int64_t *__restrict__ out_hits,
+                                                      double *__restrict__ out_sum)
+{
+    eval_ranked_body(ranked, cnt, test_sorted, n_test, terms, out_hits, out_sum);
+}
+// one block per seed of a batch: row k of the ranked-list table against test set k (CSR)
+__global__ __launch_bounds__(1024) void k_eval_ranked_batch(const int64_t *__restrict__ ranked, int64_t row_stride,
+                                                            const int32_t *__restrict__ counts,
+                                                            const int64_t *__restrict__ test_sorted,
+                                                            const int64_t *__restrict__ test_ptr, double *__restrict__ terms,
+                                                            int64_t *__restrict__ out_hits, double *__restrict__ out_sum)
+{
+    const int k = blockIdx.x;
+    const int64_t t0 = test_ptr[k];
+    eval_ranked_body(ranked + (size_t)k * row_stride, counts[k], test_sorted + t0, (int32_t)(test_ptr[k + 1] - t0), terms + t0,
+                     out_hits + k, out_sum + k);
+}
+
 int32_t eval_ranked(rwr_graph *g, int32_t cnt, const int64_t *test_sorted_host, int64_t n_test, int64_t *n_hits,
                     double *sum_precision)
 {
@@ -530,6 +550,31 @@ int32_t eval_ranked(rwr_graph *g, int32_t cnt, const int64_t *test_sorted_host, 
     RWR_HIP(hipGetLastError());
     RWR_HIP(hipMemcpyAsync(n_hits, d_hits.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     RWR_HIP(hipMemcpyAsync(sum_precision, d_sum.p, sizeof(double), hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipStreamSynchronize(s));
+    return RWR_OK;
+}
+
+// K ranked lists (rows of d_out_id, `row_stride` apart, lengths in d_counts) against K test sets given in CSR form, each
+// already sorted and de-duplicated by the caller
+int32_t eval_ranked_batch(rwr_graph *g, int32_t K, int64_t row_stride, const int64_t *test_ptr_host,
+                          const int64_t *test_sorted_host, int64_t *n_hits, double *sum_precision)
+{
+    hipStream_t s = g->stream;
+    const int64_t total = test_ptr_host[K];
+    DevBuf<int64_t> d_test, d_ptr, d_hits;
+    DevBuf<double> d_terms, d_sum;
+    RWR_TRY(d_test.alloc((size_t)total));
+    RWR_TRY(d_terms.alloc((size_t)total));
+    RWR_TRY(d_ptr.alloc((size_t)K + 1));
+    RWR_TRY(d_hits.alloc((size_t)K));
+    RWR_TRY(d_sum.alloc((size_t)K));
+    if (total > 0) RWR_HIP(hipMemcpyAsync(d_test.p, test_sorted_host, sizeof(int64_t) * (size_t)total, hipMemcpyHostToDevice, s));
+    RWR_HIP(hipMemcpyAsync(d_ptr.p, test_ptr_host, sizeof(int64_t) * ((size_t)K + 1), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_eval_ranked_batch, dim3((unsigned)K), dim3(1024), 0, s, g->d_out_id.p, row_stride, g->d_counts.p, d_test.p,
+                       d_ptr.p, d_terms.p, d_hits.p, d_sum.p);
+    RWR_HIP(hipGetLastError());
+    RWR_HIP(hipMemcpyAsync(n_hits, d_hits.p, sizeof(int64_t) * (size_t)K, hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipMemcpyAsync(sum_precision, d_sum.p, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, s));
     RWR_HIP(hipStreamSynchronize(s));
     return RWR_OK;
 }

@@ -156,20 +156,31 @@ class HipSlabBackend:
 MAX_TILE = 64      # seeds per rank-matrix tile of the row-partitioned mode (rwr_part_begin)
 
 
-def reduce_scatter_slabs(t, G: int, bounds, rank: int, group=None):
+def reduce_scatter_slabs(t, G: int, bounds, rank: int, group=None, recv=None):
     """Reduce-scatter(sum) of the partial rank matrix t[n * G] by the (uneven) node slabs: afterwards rank r holds the
     complete rows [bounds[r], bounds[r + 1]) of the sum in place; the rest of t is unspecified (never read again).
-    Uneven slabs = one reduce per destination rank (what an uneven NCCL reduce-scatter is made of; gloo has reduce too)."""
+
+    ONE collective per call: an all-to-all with uneven splits -- every rank sends slab j of its partial matrix to rank j,
+    i.e. (w - 1) / w of the matrix leaves each rank, on a full mesh one slab per peer link (the direct
+    reduce-scatter) -- followed by a LOCAL sum of the w received pieces in rank order, which makes the result independent
+    of the collective's internal schedule (deterministic from run to run).  `recv` (optional) is a reusable buffer of at
+    least w * (own slab) * G elements; returns the buffer used."""
+    import torch
     import torch.distributed as dist
     world = len(bounds) - 1
-    works = []
-    for r in range(world):
-        lo, hi = int(bounds[r]) * G, int(bounds[r + 1]) * G
-        if hi > lo:
-            works.append(dist.reduce(t[lo:hi], dst=dist.get_global_rank(group, r) if group is not None else r,
-                                     group=group, async_op=True))
-    for w in works:
-        w.wait()
+    in_splits = [(int(bounds[r + 1]) - int(bounds[r])) * G for r in range(world)]
+    own = in_splits[rank]
+    if recv is None or recv.numel() < world * own or recv.dtype != t.dtype or recv.device != t.device:
+        recv = torch.empty(max(world * own, 1), dtype=t.dtype, device=t.device)
+    out = recv[:world * own]
+    dist.all_to_all_single(out, t, output_split_sizes=[own] * world, input_split_sizes=in_splits, group=group)
+    if own > 0:
+        pieces = out.view(world, own)
+        dst = t[int(bounds[rank]) * G:int(bounds[rank + 1]) * G]
+        dst.copy_(pieces[0])
+        for r in range(1, world):                     # rank order: a fixed summation order
+            dst.add_(pieces[r])
+    return recv
 
 
 class PartitionedRecommender:
@@ -183,15 +194,19 @@ class PartitionedRecommender:
         factory = backend_factory or HipSlabBackend
         self.backend = factory(local, self.lo, self.hi, **opts)
         self.exchanged_bytes = 0          # payload handed to collectives by this rank (measurement)
+        self.collectives = 0              # data-path collectives issued by this rank (one per iteration)
+        self._recv = None                 # receive buffer of the slab exchange (w pieces of this rank's slab)
 
     def _all_reduce(self, t):
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(t, group=self.group)      # sum; RCCL over xGMI on GPUs
+            self.collectives += 1
 
     def _reduce_scatter(self, t, G):
         if self.world > 1:
-            reduce_scatter_slabs(t, G, self.bounds, self.rank, self.group)
+            self._recv = reduce_scatter_slabs(t, G, self.bounds, self.rank, self.group, self._recv)
+            self.collectives += 1
 
     def RecommendationBatch(self, seeds, dampingFactor: float, nIteration: int, topN: int):
         """Same result (to tolerance) on every rank as Recommender.RecommendationBatch on one GPU.

@@ -72,6 +72,8 @@ class Graph:
     (kept by reference, Graph.cs:46-47); ``buildGraph()`` hands the RAW links to
     rwr_graph_create, which filters/normalises/transposes on the device."""
 
+    incremental_rebuilds = 0     # buildGraph() calls (all instances) that went through rwr_graph_update_links
+
     def __init__(self, nodes: Dict[int, Node], edges: Dict[int, List[ForwardLink]], *, mode: Optional[str] = None,
                  device: int = -1, tile_seeds: int = 0, tile_group: int = 0, profile: bool = False,
                  workspace_bytes: int = 0, seed_row_kernel: Optional[str] = None):
@@ -136,6 +138,7 @@ class Graph:
                 changed = np.flatnonzero((o_etype != etype) | (o_w.view(np.uint64) != w.view(np.uint64))).astype(np.int64)
                 self.updateLinks(changed, etype[changed], w[changed])
                 self._sent = flat
+                Graph.incremental_rebuilds += 1
                 return
         if self._h:
             lib.rwr_graph_destroy(self._h)
@@ -370,6 +373,25 @@ class Recommender:
                                                   int(nIteration), _p(t, C.c_int64), len(t), C.byref(hits),
                                                   C.byref(sp), C.byref(ln)))
         return int(hits.value), float(sp.value), int(ln.value)
+
+    def RecommendationEvalBatch(self, seeds, dampingFactor: float, nIteration: int, testSets):
+        """RecommendationEval for K seeds of this graph, each with its own test set (rwr_recommend_eval_batch):
+        returns (nHits[K], sumPrecision[K], listLen[K])."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        K = int(seeds.shape[0])
+        if len(testSets) != K:
+            raise ValueError("one test set per seed")
+        ptr = np.zeros(K + 1, dtype=np.int64)
+        for k, t in enumerate(testSets):
+            ptr[k + 1] = ptr[k] + len(t)
+        ids = np.ascontiguousarray([x for t in testSets for x in t], dtype=np.int64) if ptr[K] else np.zeros(1, dtype=np.int64)
+        hits = np.zeros(K, dtype=np.int64)
+        sp = np.zeros(K, dtype=np.float64)
+        ln = np.zeros(K, dtype=np.int64)
+        _lib.check(_lib.load().rwr_recommend_eval_batch(self.graph._handle(), _p(seeds, C.c_int32), K, C.c_float(dampingFactor),
+                                                        int(nIteration), _p(ptr, C.c_int64), _p(ids, C.c_int64),
+                                                        _p(hits, C.c_int64), _p(sp, C.c_double), _p(ln, C.c_int64)))
+        return hits, sp, ln
 
     def RecommendationBatch(self, seeds, dampingFactor: float, nIteration: int, topN: int):
         """Batch entry (an addition, see include/rwr.h): (ids[K,topN], scores[K,topN], counts[K])."""

@@ -7,8 +7,7 @@ import pytest
 
 from tests import tweet_harness as th
 
-METHODS = [th.BASELINE, th.INCL_FRIENDSHIP, th.INCL_MENTIONCOUNT, th.ALL, th.EXCL_FRIENDSHIP,
-           th.INCL_FOLLOWSHIP_ON_THIRDPARTY_AND_AUTHORSHIP]
+METHODS = list(range(16))          # every Methodology of Experiment.cs:7-15 / DataLoader.cs:144-212
 
 
 @pytest.fixture(scope="module")
@@ -33,11 +32,26 @@ def test_loader_builds_a_valid_ego_network(db):
     assert len(lines) == 1 and lines[0].split("\t")[:4] == ["1000", "0", "3", "5"]
 
 
+def test_all_sixteen_methodologies_on_the_oracle(db):
+    """The 16 feature sets give 16 result lines; the three relabel cases (Experiment.cs:84-101) leave no FRIENDSHIP link in
+    the walk, and building before or after the relabel is the same graph for the oracle's classes too."""
+    api = th.oracle_api()
+    a_lines, a_lists = th.run_k_fold(api, db, 1000, METHODS, 3, 10)
+    b_lines, b_lists = th.run_k_fold(api, db, 1000, list(th.RELABEL), 3, 10, relabel_after_build=True)
+    assert len(a_lines) == 16 and [l.split("\t")[1] for l in a_lines] == [str(m) for m in METHODS]
+    assert b_lines == [a_lines[m] for m in th.RELABEL]
+    assert len({l.split("\t", 2)[2] for l in a_lines}) > 4      # the feature sets do change the outcome
+
+
 @pytest.mark.gpu
 def test_result_dat_identical_on_gpu_and_oracle(db):
+    import recommendersystems_amd as amd
     o_lines, o_lists = th.run_k_fold(th.oracle_api(), db, 1000, METHODS, 3, 10)
     ev = lambda rec, test, T: rec.RecommendationEval(0, 0.15, T, test)
-    g_lines, g_lists = th.run_k_fold(th.gpu_api(), db, 1000, METHODS, 3, 10, evaluate=ev)
+    before = amd.Graph.incremental_rebuilds
+    g_lines, g_lists = th.run_k_fold(th.gpu_api(), db, 1000, METHODS, 3, 10, evaluate=ev, relabel_after_build=True)
+    # the three FRIENDSHIP -> UNDEFINED methodologies were rebuilt in place (rwr_graph_update_links), once per fold
+    assert amd.Graph.incremental_rebuilds - before == 3 * len(th.RELABEL)
     assert g_lines == o_lines                                  # hits and MAP identical to the last bit
     for (m, f, a), (_, _, b) in zip(o_lists, g_lists):
         assert [x[0] for x in a] == [x[0] for x in b], (m, f)

@@ -331,6 +331,44 @@ def test_recommend_eval_bitwise(amd):
     assert amd.Recommender(G).RecommendationEval(0, 0.15, 3, set())[:2] == (0, 0.0)
 
 
+def test_recommend_eval_batch_bitwise(amd):
+    """rwr_recommend_eval_batch: K seeds with K test sets (CSR) -- entry k equals the single-seed call and the oracle's
+    evaluation of the oracle's full list: empty sets, duplicates, ids that are no items, a dangling seed, K = 1."""
+    from oracle.c_oracle import evaluate as c_eval
+    g = gg.random_graph(62, n_users=300, n_items=2500, n_likes=9000, n_friend=150, n_mention=80)
+    et = g["etype"].copy()
+    et[g["rowptr"][7]:g["rowptr"][8]] = gg.EDGE_UNDEFINED          # user 7 becomes dangling
+    g = dict(g, etype=et)
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g)
+    rec = amd.Recommender(G)
+    rng = np.random.default_rng(3)
+    item_ids = g["node_id"][g["node_type"] == gg.NODE_ITEM]
+    seeds = np.array([0, 7, 57, 299, 120, 0, 33], dtype=np.int32)
+    tests = []
+    for k in range(len(seeds)):
+        t = rng.choice(item_ids, int(rng.integers(0, 60)), replace=False).tolist()
+        if k == 2:
+            t = t + t[:5] + [-9, 10 ** 15]                            # duplicates and ids that are no items
+        if k == 4:
+            t = []
+        tests.append(t)
+    hits, sp, ln = rec.RecommendationEvalBatch(seeds, 0.15, 8, tests)
+    for k, sd in enumerate(seeds):
+        ids, _ = F.recommend(int(sd), 0.15, 8)
+        oh, osp = c_eval(ids, sorted(set(tests[k])))
+        assert ln[k] == len(ids) and hits[k] == oh, k
+        assert np.float64(sp[k]).view(np.uint64) == np.float64(osp).view(np.uint64), k
+        one = rec.RecommendationEval(int(sd), 0.15, 8, set(tests[k]))
+        assert one == (int(hits[k]), float(sp[k]), int(ln[k])), k
+    h1, s1, l1 = rec.RecommendationEvalBatch(seeds[:1], 0.15, 8, tests[:1])
+    assert (h1[0], s1[0], l1[0]) == (hits[0], sp[0], ln[0])
+    h0, s0, l0 = rec.RecommendationEvalBatch(seeds[:0], 0.15, 8, [])
+    assert len(h0) == 0
+    with pytest.raises(Exception):
+        rec.RecommendationEvalBatch(np.array([0, 99999], dtype=np.int32), 0.15, 8, [[], []])
+
+
 def test_cpp_host_mirror_runs_the_kats():
     """include/recommenders/rwr_based.hpp + tests/cpp/experiment_like.cpp: the caller pattern of
     Experiment.cs:104-128 in C++ against librwr (built by __graft_entry__.build())."""

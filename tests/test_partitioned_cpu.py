@@ -72,6 +72,7 @@ def _worker(rank, world, port, q):
         ok1 = bool((cnt == oc).all() and (ids == oi).all() and np.abs(sc - os_).max() <= 1e-9)
         # exchange volume: T - 1 reduce-scatters + 1 all-reduce of the n x K matrix (an all-reduce moves twice that)
         ok1 = ok1 and pr.exchanged_bytes == 10 * len(g["node_id"]) * len(seeds) * 8
+        ok1 = ok1 and pr.collectives == 10                       # ONE data-path collective per iteration
         # a batch beyond one 64-seed tile runs tile after tile
         many = (np.arange(70, dtype=np.int64) * 60 // 70).astype(np.int32)
         mi, ms, mc = pr.RecommendationBatch(many, 0.15, 4, 5)

@@ -241,9 +241,17 @@ class DataLoader:                                            # DataLoader.cs
         self.db.closeDB()
 
 
-def run_k_fold(api: Api, db_path: str, ego: int, methodologies, nFolds: int, nIterations: int, evaluate=None):
+RELABEL = (INCL_MENTIONCOUNT, EXCL_FRIENDSHIP, INCL_FOLLOWSHIP_ON_THIRDPARTY_AND_MENTIONCOUNT)   # Experiment.cs:84-86
+
+
+def run_k_fold(api: Api, db_path: str, ego: int, methodologies, nFolds: int, nIterations: int, evaluate=None,
+               relabel_after_build=False):
     """Experiment.runKFoldCrossValidation, Experiment.cs:46-155.  Returns the result.dat lines (one per methodology)
-    and, for inspection, the per-fold ranked lists."""
+    and, for inspection, the per-fold ranked lists.
+    relabel_after_build: for the three methodologies whose FRIENDSHIP links are relabelled UNDEFINED (Experiment.cs:84-101)
+    the graph is FIRST built with the links as loaded and rebuilt after the in-place relabel -- the path a host takes when
+    it keeps one Graph object per ego network and only the link types change between runs; on the GPU mirror the second
+    buildGraph() goes through rwr_graph_update_links.  The result must be what building after the relabel gives."""
     lines, lists = [], []
     for methodology in methodologies:
         hits_total, ap_total, cntLikes = 0.0, 0.0, 0
@@ -255,12 +263,17 @@ def run_k_fold(api: Api, db_path: str, ego: int, methodologies, nFolds: int, nIt
                 cntLikes = loader.cntLikesOfEgoUser
             loader.graphConfiguration(methodology, fold)
             nodes, edges = loader.allNodes, loader.allLinks
-            if methodology in (INCL_MENTIONCOUNT, EXCL_FRIENDSHIP, INCL_FOLLOWSHIP_ON_THIRDPARTY_AND_MENTIONCOUNT):   # :84-101
+            graph = None
+            if relabel_after_build and methodology in RELABEL:
+                graph = api.Graph(nodes, edges)
+                graph.buildGraph()
+            if methodology in RELABEL:                       # :84-101
                 for forwardLinks in edges.values():
                     for l in forwardLinks:
                         if l.type == api.FRIENDSHIP:
                             l.type = api.UNDEFINED
-            graph = api.Graph(nodes, edges)                  # :104-105
+            if graph is None:
+                graph = api.Graph(nodes, edges)              # :104-105
             graph.buildGraph()
             recommender = api.Recommender(graph)             # :108-109
             recommendation = recommender.Recommendation(0, 0.15, nIterations)
