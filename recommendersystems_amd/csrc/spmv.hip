@@ -387,11 +387,15 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
         fork();
         const unsigned grid = (unsigned)(nh < 4096 ? nh : 4096);
         static const int prefix = [] { const char *e = getenv("RWR_HUB_PREFIX"); return e ? atoi(e) : 256; }();
+        // beside the sweep kernel: ask for 36 KB of (unused) LDS per workgroup, more than a CU has left beside a sweep
+        // workgroup (160 - 128 KB), so that the hub rows run on the CUs the sweep leaves free (sweep.hip: RWR_SWEEP_WGS)
+        static const int hub_lds_env = [] { const char *e = getenv("RWR_HUB_LDS"); return e ? atoi(e) : 36864; }();
+        const size_t hub_lds = sweep ? (size_t)hub_lds_env : 0;
         if (vf)
-            hipLaunchKernelGGL(k_spmv_exact_hub<true>, dim3(grid), dim3(WAVE), 0, g->stream3, ra, ra + nh, g->in_ptr.p, g->in_src.p,
+            hipLaunchKernelGGL(k_spmv_exact_hub<true>, dim3(grid), dim3(WAVE), hub_lds, g->stream3, ra, ra + nh, g->in_ptr.p, g->in_src.p,
                                g->in_w.p, order, gs, Y, seeds, c1, skip, g->w_src.p, zout, prefix);
         else
-            hipLaunchKernelGGL(k_spmv_exact_hub<false>, dim3(grid), dim3(WAVE), 0, g->stream3, ra, ra + nh, g->in_ptr.p, g->in_src.p,
+            hipLaunchKernelGGL(k_spmv_exact_hub<false>, dim3(grid), dim3(WAVE), hub_lds, g->stream3, ra, ra + nh, g->in_ptr.p, g->in_src.p,
                                g->in_w.p, order, gs, Y, seeds, c1, skip, g->w_src.p, zout, prefix);
     };
     auto blocks_for = [](int64_t rows, int W) { const int64_t b = (rows * W + 255) / 256; return (int)(b < 0 ? 0 : (b > 16384 ? 16384 : b)); };

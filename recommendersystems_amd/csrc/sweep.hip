@@ -354,7 +354,15 @@ int32_t sweep_prepare(rwr_graph *g)
     const int wpg = 8;                                     // waves per workgroup (512 threads: up to 256 registers per lane)
     hipDeviceProp_t prop;
     RWR_HIP(hipGetDeviceProperties(&prop, g->device));
-    const int nwg = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // workgroups of the sweep (one per CU, each holding its CU's LDS): a share of the CUs is left to the hub-row kernel, whose
+    // workgroups ask for more LDS than a CU has left beside a sweep workgroup and therefore land on the other CUs -- the two
+    // kernels then never share a SIMD (sharing one slowed both: 93 us beside 88 us standalone became 184 us together)
+    static const int wgs_env = [] { const char *e = getenv("RWR_SWEEP_WGS"); return e ? atoi(e) : 0; }();
+    const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int32_t n_hub = g->x_hub[0] + g->x_hub[1];
+    int nwg = wgs_env > 0 ? wgs_env : (n_hub > 0 ? (ncu * 5) / 8 : ncu);
+    if (nwg > ncu) nwg = ncu;
+    if (nwg < 1) nwg = 1;
     const int nw = nwg * wpg;
     // sweep order: the two-phase in-degree order (engine.h: row_order_x -- ITEM rows, then the others, each by in-degree
     // descending) without its hub rows.  The 64 rows of a slot then gather from the same region of the rank vector (an
