@@ -301,7 +301,7 @@ static double bt_now()
     using namespace std::chrono;
     return duration<double, std::micro>(steady_clock::now().time_since_epoch()).count();
 }
-static const bool bt_on = [] { const char *e = getenv("RWR_BUILD_TIMING"); return e && atoi(e) != 0; }();
+static const bool bt_on = [] { const char *e = RWR_TUNE_ENV("RWR_BUILD_TIMING"); return e && atoi(e) != 0; }();
 #define BT(label) do { if (bt_on) { const double t__ = bt_now(); fprintf(stderr, "[build] %-28s %8.1f us\n", label, t__ - bt_t); bt_t = t__; } } while (0)
 
 // uploads the RAW lists (they stay resident: the exclusion list reads them, Recommender.cs:20-24, and an incremental
@@ -351,7 +351,7 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
     RWR_TRY(g->item_rows.alloc(n_items));
 
     BT("host prep + allocs");
-    static const int stage_env = [] { const char *e = getenv("RWR_STAGE"); return e ? atoi(e) : 1; }();
+    static const int stage_env = [] { const char *e = RWR_TUNE_ENV("RWR_STAGE"); return e ? atoi(e) : 1; }();
     g->staged = stage_env && n <= STAGE_MAX_N && m <= STAGE_MAX_M;
     if (g->staged) {
         if (!g->sm_stage) RWR_HIP(hipHostMalloc(&g->sm_stage, STAGE_BYTES, hipHostMallocMapped | hipHostMallocPortable));
@@ -505,7 +505,7 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     }
 
     // destination-row processing order (in-degree descending) and ITEM rows by id descending
-    const char *om = getenv("RWR_ROW_ORDER");
+    const char *om = RWR_TUNE_ENV("RWR_ROW_ORDER");
     const int order_mode = om ? atoi(om) : 0;
     DevBuf<uint64_t> ikey, ikey2;
     DevBuf<uint32_t> ival, ival2;

@@ -485,7 +485,7 @@ static int32_t chain_scan_launch(rwr_graph *g, int G, int tg, const double *X, d
 {
     const int nchunks = cs_nchunks(g->n, G);
     const dim3 grid((unsigned)nchunks, (unsigned)tg);
-    static const int direct_max = [] { const char *e = getenv("RWR_SCAN_DIRECT_BLOCKS"); return e ? atoi(e) : 8; }();
+    static const int direct_max = [] { const char *e = RWR_TUNE_ENV("RWR_SCAN_DIRECT_BLOCKS"); return e ? atoi(e) : 8; }();
     if (nchunks <= direct_max) {
         CS_DISPATCH_G(G, hipLaunchKernelGGL(k_cs_carry<GG>, dim3((unsigned)(tg * G)), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y,
                                             d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, lnk,

@@ -30,6 +30,16 @@ void set_error(const char *fmt, ...);
 
 constexpr int WAVE = 64;
 
+// Tuning knobs (thresholds and A/B switches used while measuring) are read from the environment only by the experiments
+// build (make exp, -DRWR_EXPERIMENTS: tools/ only, never shipped); the shipped library runs their defaults.  What it does
+// read -- RWR_DEVICE, RWR_MODE and the selectors between equivalent correct code paths that the parity tests drive
+//  -- goes through plain getenv.
+#ifdef RWR_EXPERIMENTS
+#define RWR_TUNE_ENV(NAME) getenv(NAME)
+#else
+#define RWR_TUNE_ENV(NAME) ((const char *)nullptr)
+#endif
+
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 // order-preserving map of a non-NaN double to uint64 (ascending); -0.0 is first

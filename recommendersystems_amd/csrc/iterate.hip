@@ -805,7 +805,7 @@ struct GroupIter {
         if (fresh && Zc) RWR_HIP(hipMemsetAsync(Zc, 0, elems * sizeof(double), s));
         if (!fresh && Zc) hipLaunchKernelGGL(k_make_z, dim3(cdiv(elems, 256)), dim3(256), 0, s, (int64_t)elems, G, X, Zc, g->w_src.p, c1);
         // frontier bitmaps for the first iterations (chunked SpMM only)
-        static const int nz_iters_env = [] { const char *e = getenv("RWR_NZ_ITERS"); return e ? atoi(e) : 4; }();
+        static const int nz_iters_env = [] { const char *e = RWR_TUNE_ENV("RWR_NZ_ITERS"); return e ? atoi(e) : 4; }();
         static const int spmm_variant = [] { const char *e = getenv("RWR_SPMM"); return e ? atoi(e) : 1; }();
         // (skipping +0.0 addends is only a bitwise no-op while every accumulator is >= +0.0: weights must be >= 0)
         nz_iters = (G >= 8 && spmm_variant != 0 && g->nonneg) ? nz_iters_env : 0;
@@ -836,7 +836,7 @@ struct GroupIter {
         // auto: per step the fold costs ~10 ns per node whatever the batch (hidden if the SpMM is longer); the scan
         // costs ~6.7 ps per (node, seed) on top of an SpMM of ~0.89 ps per (link, seed)  (measured, MI355X, 20 M- and
         // 200 M-link graphs) => scan while  seeds * (0.89 * links/node + 6.7) < 10000  (about 280 seeds there)
-        static const double scan_work = [] { const char *e = getenv("RWR_SCAN_WORK"); return e ? atof(e) : 10000.0; }();
+        static const double scan_work = [] { const char *e = RWR_TUNE_ENV("RWR_SCAN_WORK"); return e ? atof(e) : 10000.0; }();
         const int sel = g->opts.seed_row_kernel;
         chain_kind = sel == 1 ? 3 : sel == 2 ? 2 : sel == 3 ? 0 : chain_env;
         const double per_seed = 0.89 * (double)g->nnz / (double)(g->n > 0 ? g->n : 1) + 6.7;
@@ -858,8 +858,8 @@ struct GroupIter {
         const bool prof = g->opts.profile != 0;
         const size_t nzw = ((size_t)n + 31) / 32;
         constexpr int GATE_SLOTS = 64;
-        static const int use_gate = [] { const char *e = getenv("RWR_GATE"); return e ? atoi(e) : 1; }();
-        static const int serial = [] { const char *e = getenv("RWR_CHAIN_SERIAL"); return e ? atoi(e) : 0; }();
+        static const int use_gate = [] { const char *e = RWR_TUNE_ENV("RWR_GATE"); return e ? atoi(e) : 1; }();
+        static const int serial = [] { const char *e = RWR_TUNE_ENV("RWR_CHAIN_SERIAL"); return e ? atoi(e) : 0; }();
         unsigned int *gate_it = nullptr;
         const uint32_t *nz_in = (it < nz_iters) ? nz_cur : nullptr;
         uint32_t *nz_out = (it + 1 < nz_iters) ? nz_oth : nullptr;
@@ -879,7 +879,7 @@ struct GroupIter {
             // on the second stream BESIDE the SpMV -- the two read the same vectors and write disjoint rows, and for one seed
             // the chain's five small kernels take as long as the SpMV itself (C2: ~100 us each), so the step costs their
             // maximum instead of their sum.
-            static const int side_env = [] { const char *e = getenv("RWR_SCAN_SIDE"); return e ? atoi(e) : 1; }();
+            static const int side_env = [] { const char *e = RWR_TUNE_ENV("RWR_SCAN_SIDE"); return e ? atoi(e) : 1; }();
             // (only on graphs large enough for the kernels to outlast the fork / join: measured -29 % per call at 224 K nodes,
             //  neutral at 120 K, +19 % at 12 K)
             scan_side = side_env && G == 1 && tg == 1 && s2 != s && g->n >= 100000;
@@ -1139,7 +1139,7 @@ int32_t recommend_batch(rwr_graph *g, const int32_t *seeds, int32_t K, double d,
         hipLaunchKernelGGL(k_exclude, dim3((unsigned)(tg * G)), dim3(64), 0, s, n, tg, G, g->rowptr.p,
                            g->dst.p, g->etype.p, Xf, dseeds);
         RWR_HIP(hipGetLastError());
-        static const int force_sort = [] { const char *e = getenv("RWR_RANK_SORT"); return e ? atoi(e) : 0; }();
+        static const int force_sort = [] { const char *e = RWR_TUNE_ENV("RWR_RANK_SORT"); return e ? atoi(e) : 0; }();
         if (top_n <= rank_select_max_k() && !force_sort) {
             RWR_TRY(rank_group_select(g, G, tg, g->d_slot_k.p + (size_t)t0 * G, top_n, Xf, dseeds, s));
         } else {

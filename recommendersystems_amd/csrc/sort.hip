@@ -258,7 +258,7 @@ int32_t radix_sort_pairs(KeyT *keys, KeyT *keys_alt, uint32_t *vals, uint32_t *v
         set_error("radix_sort_pairs: %d key bits do not fit a %d-bit key", key_bits, (int)(8 * sizeof(KeyT)));
         return RWR_E_INVALID;
     }
-    static const int small_env = [] { const char *e = getenv("RWR_SMALL_SORT"); return e ? atoi(e) : 1; }();
+    static const int small_env = [] { const char *e = RWR_TUNE_ENV("RWR_SMALL_SORT"); return e ? atoi(e) : 1; }();
     if (small_env && nseg == 1 && m <= SMALL_SORT_MAX) {
         hipLaunchKernelGGL(k_sort_small<KeyT>, dim3(1), dim3(SMALL_SORT_THREADS), 0, stream, keys, keys_alt, vals, vals_alt,
                            (uint32_t)m, key_bits);

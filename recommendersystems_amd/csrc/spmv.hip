@@ -360,8 +360,8 @@ __global__ __launch_bounds__(WAVE, 3) void k_spmv_exact_hub(int32_t r0, int32_t 
 void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *seeds, double c1, int skip,
                        const uint32_t *act, uint32_t *nz_out, hipStream_t s, const double *zin, double *zout, bool hub_scan)
 {
-    static const bool by_degree = [] { const char *e = getenv("RWR_ROW_ORDER"); return !e || atoi(e) == 0; }();
-    static const int group_rows = [] { const char *e = getenv("RWR_GROUP_ROWS"); return e ? atoi(e) : 2; }();
+    static const bool by_degree = [] { const char *e = RWR_TUNE_ENV("RWR_ROW_ORDER"); return !e || atoi(e) == 0; }();
+    static const int group_rows = [] { const char *e = RWR_TUNE_ENV("RWR_GROUP_ROWS"); return e ? atoi(e) : 2; }();
     // two phases pay once the rank vector no longer fits the L2s (measured: -17 % SpMV time on the 6 M-node graph, nothing on
     // the 0.6 M-node one, +10 % on the dense 0.2 M-node one, where the second launch only adds a tail)
     static const int phases_env = [] { const char *e = getenv("RWR_SPMV_PHASES"); return e ? atoi(e) : -1; }();
@@ -386,10 +386,10 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
         if (nh <= 0) return;
         fork();
         const unsigned grid = (unsigned)(nh < 4096 ? nh : 4096);
-        static const int prefix = [] { const char *e = getenv("RWR_HUB_PREFIX"); return e ? atoi(e) : 256; }();
+        static const int prefix = [] { const char *e = RWR_TUNE_ENV("RWR_HUB_PREFIX"); return e ? atoi(e) : 256; }();
         // beside the sweep kernel: ask for 36 KB of (unused) LDS per workgroup, more than a CU has left beside a sweep
         // workgroup (160 - 128 KB), so that the hub rows run on the CUs the sweep leaves free (sweep.hip: RWR_SWEEP_WGS)
-        static const int hub_lds_env = [] { const char *e = getenv("RWR_HUB_LDS"); return e ? atoi(e) : 36864; }();
+        static const int hub_lds_env = [] { const char *e = RWR_TUNE_ENV("RWR_HUB_LDS"); return e ? atoi(e) : 36864; }();
         const size_t hub_lds = sweep ? (size_t)hub_lds_env : 0;
         if (vf)
             hipLaunchKernelGGL(k_spmv_exact_hub<true>, dim3(grid), dim3(WAVE), hub_lds, g->stream3, ra, ra + nh, g->in_ptr.p, g->in_src.p,

@@ -357,7 +357,7 @@ int32_t sweep_prepare(rwr_graph *g)
     // workgroups of the sweep (one per CU, each holding its CU's LDS): a share of the CUs is left to the hub-row kernel, whose
     // workgroups ask for more LDS than a CU has left beside a sweep workgroup and therefore land on the other CUs -- the two
     // kernels then never share a SIMD (sharing one slowed both: 93 us beside 88 us standalone became 184 us together)
-    static const int wgs_env = [] { const char *e = getenv("RWR_SWEEP_WGS"); return e ? atoi(e) : 0; }();
+    static const int wgs_env = [] { const char *e = RWR_TUNE_ENV("RWR_SWEEP_WGS"); return e ? atoi(e) : 0; }();
     const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int32_t n_hub = g->x_hub[0] + g->x_hub[1];
     int nwg = wgs_env > 0 ? wgs_env : (n_hub > 0 ? (ncu * 5) / 8 : ncu);
