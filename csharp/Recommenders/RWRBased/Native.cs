@@ -33,6 +33,12 @@ namespace Recommenders.RWRBased {
             long[] out_id, double[] out_score, ref long inout_count);
         [DllImport(Lib)] public static extern int rwr_recommend_batch(GraphHandle g, int[] seeds, int K, float d, int n_iter,
             int top_n, long[] ids, double[] scores, int[] counts);
+        // Hits / sum of precisions of Experiment.cs:121-128 computed on the device (the ranked list never crosses): one seed,
+        // or K seeds with K test sets in CSR form (test set k = test_ids[test_ptr[k] .. test_ptr[k + 1]))
+        [DllImport(Lib)] public static extern int rwr_recommend_eval(GraphHandle g, int seed, float d, int n_iter, long[] test_ids,
+            long n_test, out long n_hits, out double sum_precision, out long list_len);
+        [DllImport(Lib)] public static extern int rwr_recommend_eval_batch(GraphHandle g, int[] seeds, int K, float d, int n_iter,
+            long[] test_ptr, long[] test_ids, long[] n_hits, double[] sum_precision, long[] list_len);
         [DllImport(Lib)] public static extern int rwr_model_run(GraphHandle g, int seed, double d, int run_mode, double value,
             double[] rank_out, out long iters_out);
 

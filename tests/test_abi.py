@@ -121,3 +121,15 @@ def test_csharp_shim_structs_match_the_ctypes_mirror():
     assert total == C.sizeof(L.rwr_opts) == 40
     graph_cs = open(os.path.join(ROOT, "csharp", "Recommenders", "RWRBased", "Graph.cs")).read()
     assert re.search(r"struct_size\s*=\s*40\b", graph_cs)
+    # every entry point the shim P/Invokes is one the library exports, with the parameter count of the header's declaration
+    hdr = open(os.path.join(ROOT, "include", "rwr.h")).read()
+    imports = re.findall(r"static extern \w+ (rwr_\w+)\(([^)]*)\)", src)
+    assert len(imports) >= 12
+    for name, params in imports:
+        assert name in L.EXPORTS, name
+        decl = re.search(r"^[A-Za-z_][\w \*]*\b" + name + r"\s*\(([^;]*?)\)\s*;", hdr, re.S | re.M)
+        assert decl, name
+        args = re.sub(r"/\*.*?\*/", "", decl.group(1), flags=re.S).strip()
+        n_c = 0 if args in ("", "void") else args.count(",") + 1
+        n_cs = 0 if not params.strip() else params.count(",") + 1
+        assert n_c == n_cs, (name, n_c, n_cs)

@@ -10,7 +10,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   name=$(echo $grp | cut -d' ' -f1)
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc_$name -o run -- python3 $root/tools/single_seed_latency.py $cfg exact > $out/pmc_$name.log 2>&1 || { echo "pmc $name failed"; tail -5 $out/pmc_$name.log; exit 1; }
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc_$name -o run -- python3 $root/tools/single_seed_latency.py $cfg > $out/pmc_$name.log 2>&1 || { echo "pmc $name failed"; tail -5 $out/pmc_$name.log; exit 1; }
 done
 cd $root
 python3 tools/pmc_summary.py "$cfg single seed exact (tools/single_seed_latency.py)" $out/pmc_summary.json $out/traffic_unused.json $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_TCC_HIT_sum > $out/pmc_print.log
