@@ -9,6 +9,7 @@
 // (source asc, list position asc) order, so every in-neighbour list comes out in exactly
 // the order in which Model.deliverRanks adds into nextRank[target] (Model.cs:78,85-88).
 #include "engine.h"
+#include "sort_small.h"
 
 #include <chrono>
 #include <cstdlib>
@@ -25,23 +26,24 @@ namespace rwr {
 // own -- the first version -- ran at a tenth of this: 31 of the 54 ms of the 100 M-like graph's build.)
 constexpr int RP_CAP = 2048;   // links per tile and wave
 constexpr int RP_WPB = 4;      // waves per workgroup
-__global__ __launch_bounds__(RP_WPB * WAVE) void k_row_prepare(
+#ifdef RWR_EXPERIMENTS
+__device__ unsigned long long rp_dbg[16];
+#define RP_STAMP(I) { if (r0 == 0 && lane == 0) rp_dbg[(I)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define RP_STAMP(I)
+#endif
+// (the body serves 64 rows starting at r0 with the calling wave's LDS tiles; CAP = links per tile)
+template <int CAP>
+__device__ __forceinline__ void row_prepare_body(
+    int64_t r0, int lane, double *sw, uint8_t *st, int64_t *srp, double *ssum,
     int32_t n, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ dst,
     const uint8_t *__restrict__ etype, const double *__restrict__ w, double *__restrict__ w_norm,
     int32_t *__restrict__ esrc, uint32_t *__restrict__ skey, uint32_t *__restrict__ sval,
     uint8_t *__restrict__ dangling, double *__restrict__ w_src, int *__restrict__ flags)
 {
-    __shared__ double sw_all[RP_WPB][RP_CAP];
-    __shared__ uint8_t st_all[RP_WPB][RP_CAP];
-    __shared__ int64_t srp_all[RP_WPB][WAVE + 1];
-    __shared__ double ssum_all[RP_WPB][WAVE];
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-    double *sw = sw_all[wave];
-    uint8_t *st = st_all[wave];
-    int64_t *srp = srp_all[wave];
-    double *ssum = ssum_all[wave];
-    const int64_t r0 = ((int64_t)blockIdx.x * RP_WPB + wave) * WAVE;
+    constexpr int RP_CAP = CAP;
     if (r0 >= n) return;
+    RP_STAMP(0)
     const int nrows = (n - r0) < WAVE ? (int)(n - r0) : WAVE;
     const int64_t b = rowptr[r0 + (lane < nrows ? lane : nrows)];
     const int64_t e = rowptr[r0 + (lane < nrows ? lane + 1 : nrows)];
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(RP_WPB * WAVE) void k_row_prepare(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    RP_STAMP(1)
     // ---- sweep 1: every row's explicit weights summed in list order (Graph.cs:75)
     double sum = 0.0, first = 0.0;
     int64_t n_explicit = 0;
@@ -83,13 +86,46 @@ __global__ __launch_bounds__(RP_WPB * WAVE) void k_row_prepare(
     }
     for (int64_t T0 = L0; T0 < L1 && L1 - L0 <= 8 * (int64_t)RP_CAP; T0 += RP_CAP) {
         const int64_t T1 = (T0 + RP_CAP < L1) ? T0 + RP_CAP : L1;
-        for (int64_t q = T0 + lane; q < T1; q += WAVE) {
-            sw[q - T0] = w[q];
-            st[q - T0] = etype[q];
+        // (eight loads per lane in flight: as a plain copy loop every iteration waited for its own load, and in the
+        //  one-launch build of an ego network -- one workgroup, nothing to hide latency behind -- that was 130 of 270 us)
+        for (int64_t c0 = T0; c0 < T1; c0 += 8 * WAVE) {
+            double tw[8];
+            uint8_t te[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t q = c0 + (int64_t)u * WAVE + lane;
+                const int64_t qq = q < T1 ? q : T1 - 1;
+                tw[u] = w[qq];
+                te[u] = etype[qq];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t q = c0 + (int64_t)u * WAVE + lane;
+                if (q < T1) { sw[q - T0] = tw[u]; st[q - T0] = te[u]; }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int64_t pe = e < T1 ? e : T1;
+        // (four LDS pairs fetched ahead of the adds: one entry per iteration paid two dependent LDS round trips each, and
+        //  the row's adds -- sequential by the reference's definition -- waited for them)
+        for (; p + 4 <= pe; p += 4) {
+            uint8_t ty[4];
+            double wq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ty[u] = st[p - T0 + u]; wq[u] = sw[p - T0 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ty[u] != RWR_EDGE_UNDEFINED) {
+                    const double wp = wq[u];
+                    if (n_explicit == 0) first = wp;
+                    else if (wp != first) uni = false;
+                    sum += wp;                           // Graph.cs:75, list order
+                    ++n_explicit;
+                    if (!(wp >= 0.0)) neg = true;        // negative or NaN raw weight
+                }
+            }
+        }
         for (; p < pe; ++p) {
             if (st[p - T0] != RWR_EDGE_UNDEFINED) {
                 const double wp = sw[p - T0];
@@ -103,6 +139,7 @@ __global__ __launch_bounds__(RP_WPB * WAVE) void k_row_prepare(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();                 // (the tile is overwritten next)
     }
+    RP_STAMP(2)
     ssum[lane] = sum;
     if (lane < nrows) {
         dangling[r0 + lane] = (n_explicit == 0) ? 1 : 0;             // Graph.cs:64,86
@@ -111,45 +148,90 @@ __global__ __launch_bounds__(RP_WPB * WAVE) void k_row_prepare(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // ---- sweep 2: per-link outputs, coalesced
+    // ---- sweep 2: per-link outputs, coalesced; four links per lane in flight (in the one-launch build of an ego network a
+    // single workgroup runs this, and one link per lane and iteration paid a memory round trip each: 170 of its 270 us)
     bool bad = false;
-    for (int64_t q = L0 + lane; q < L1; q += WAVE) {
-        int lo = 0, hi = nrows - 1;                      // the row holding link q: largest i with srp[i] <= q
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (srp[mid] <= q) lo = mid; else hi = mid - 1;
+    constexpr int SW2_U = 4;
+    for (int64_t q0 = L0 + lane; q0 < L1; q0 += (int64_t)WAVE * SW2_U) {
+        uint8_t et[SW2_U];
+        int32_t tt[SW2_U];
+        double ww[SW2_U];
+#pragma unroll
+        for (int u = 0; u < SW2_U; ++u) {
+            const int64_t q = q0 + (int64_t)u * WAVE;
+            const int64_t qq = q < L1 ? q : L1 - 1;
+            et[u] = etype[qq];
+            tt[u] = dst[qq];
+            ww[u] = w[qq];
         }
-        const bool ex = etype[q] != RWR_EDGE_UNDEFINED;
-        const int32_t t = dst[q];
-        if (t < 0 || t >= n) bad = true;
-        w_norm[q] = ex ? w[q] / ssum[lo] : 0.0;          // Graph.cs:81
-        esrc[q] = (int32_t)(r0 + lo);
-        skey[q] = (ex && t >= 0 && t < n) ? (uint32_t)t : (uint32_t)n;   // UNDEFINED -> sentinel row n
-        sval[q] = (uint32_t)q;
+#pragma unroll
+        for (int u = 0; u < SW2_U; ++u) {
+            const int64_t q = q0 + (int64_t)u * WAVE;
+            if (q < L1) {
+                int lo = 0, hi = nrows - 1;                  // the row holding link q: largest i with srp[i] <= q
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (srp[mid] <= q) lo = mid; else hi = mid - 1;
+                }
+                const bool ex = et[u] != RWR_EDGE_UNDEFINED;
+                const int32_t t = tt[u];
+                if (t < 0 || t >= n) bad = true;
+                w_norm[q] = ex ? ww[u] / ssum[lo] : 0.0;     // Graph.cs:81
+                esrc[q] = (int32_t)(r0 + lo);
+                skey[q] = (ex && t >= 0 && t < n) ? (uint32_t)t : (uint32_t)n;   // UNDEFINED -> sentinel row n
+                sval[q] = (uint32_t)q;
+            }
+        }
     }
+    RP_STAMP(3)
     if (!uni) atomicOr(&flags[0], 1);
     if (bad) atomicOr(&flags[1], 1);
     if (lane < nrows && (neg || (n_explicit > 0 && !(sum > 0.0 && sum < __longlong_as_double(0x7ff0000000000000ll))))) atomicOr(&flags[3], 1);
 }
 
-// in_ptr[j] = first sorted position whose key >= j   (keys sorted ascending, sentinel n last)
-__global__ __launch_bounds__(256) void k_in_ptr(const uint32_t *__restrict__ skey, int64_t m, int32_t n,
-                                                int64_t *__restrict__ in_ptr)
+__global__ __launch_bounds__(RP_WPB * WAVE) void k_row_prepare(
+    int32_t n, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ dst,
+    const uint8_t *__restrict__ etype, const double *__restrict__ w, double *__restrict__ w_norm,
+    int32_t *__restrict__ esrc, uint32_t *__restrict__ skey, uint32_t *__restrict__ sval,
+    uint8_t *__restrict__ dangling, double *__restrict__ w_src, int *__restrict__ flags)
 {
-    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double sw_all[RP_WPB][RP_CAP];
+    __shared__ uint8_t st_all[RP_WPB][RP_CAP];
+    __shared__ int64_t srp_all[RP_WPB][WAVE + 1];
+    __shared__ double ssum_all[RP_WPB][WAVE];
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+    row_prepare_body<RP_CAP>(((int64_t)blockIdx.x * RP_WPB + wave) * WAVE, lane, sw_all[wave], st_all[wave], srp_all[wave], ssum_all[wave],
+                             n, rowptr, dst, etype, w, w_norm, esrc, skey, sval, dangling, w_src, flags);
+}
+
+// in_ptr[j] = first sorted position whose key >= j   (keys sorted ascending, sentinel n last)
+// (the element-wise bodies below are shared by the one-element-per-thread kernels of the general build and by the one-launch
+//  build of ego-network-sized graphs, k_build_small)
+__device__ __forceinline__ void in_ptr_body(int64_t p, const uint32_t *__restrict__ skey, int64_t m, int32_t n,
+                                            int64_t *__restrict__ in_ptr)
+{
     if (p > m) return;
     // boundary between position p-1 and p
     int64_t lo = (p == 0) ? -1 : (int64_t)skey[p - 1];
     int64_t hi = (p == m) ? (int64_t)n : (int64_t)skey[p];
     for (int64_t j = lo + 1; j <= hi; ++j) in_ptr[j] = p;
 }
+__global__ __launch_bounds__(256) void k_in_ptr(const uint32_t *__restrict__ skey, int64_t m, int32_t n,
+                                                int64_t *__restrict__ in_ptr)
+{
+    in_ptr_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, skey, m, n, in_ptr);
+}
 
+// (nnz_dev != nullptr: the number of explicit links is read on the device -- in_ptr[n] -- and `nnz` is only the launch's upper
+//  bound: ego-network-sized graphs are built without a host round trip in the middle)
 __global__ __launch_bounds__(256) void k_gather_in(const uint32_t *__restrict__ sval, int64_t nnz,
                                                    const int32_t *__restrict__ esrc,
                                                    const double *__restrict__ w_norm,
-                                                   int32_t *__restrict__ in_src, double *__restrict__ in_w)
+                                                   int32_t *__restrict__ in_src, double *__restrict__ in_w,
+                                                   const int64_t *__restrict__ nnz_dev = nullptr)
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (nnz_dev) nnz = *nnz_dev;
     if (p >= nnz) return;
     uint32_t e = sval[p];
     in_src[p] = esrc[e];
@@ -164,13 +246,9 @@ __global__ __launch_bounds__(256) void k_fill_in_w(int64_t nnz, const int32_t *_
     if (p < nnz) in_w[p] = w_src[in_src[p]];
 }
 
-__global__ __launch_bounds__(256) void k_order_keys(int32_t n, const int64_t *__restrict__ in_ptr,
-                                                    const uint8_t *__restrict__ node_type,
-                                                    const int64_t *__restrict__ node_id,
-                                                    uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval,
-                                                    int *__restrict__ maxdeg, int order_mode, uint32_t top)
+__device__ __forceinline__ void order_keys_body(int32_t i, int32_t n, const int64_t *__restrict__ in_ptr, uint32_t *__restrict__ dkey,
+                                                uint32_t *__restrict__ dval, int *__restrict__ maxdeg, int order_mode, uint32_t top)
 {
-    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t deg = (uint32_t)(in_ptr[i + 1] - in_ptr[i]);
     // ascending sort of (top - deg) == in-degree descending (top = the link count, an upper bound of every in-degree: the
@@ -180,19 +258,32 @@ __global__ __launch_bounds__(256) void k_order_keys(int32_t n, const int64_t *__
     dval[i] = (uint32_t)i;
     atomicMax(maxdeg, (int)deg);
 }
+__global__ __launch_bounds__(256) void k_order_keys(int32_t n, const int64_t *__restrict__ in_ptr,
+                                                    const uint8_t *__restrict__ node_type,
+                                                    const int64_t *__restrict__ node_id,
+                                                    uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval,
+                                                    int *__restrict__ maxdeg, int order_mode, uint32_t top)
+{
+    order_keys_body(blockIdx.x * blockDim.x + threadIdx.x, n, in_ptr, dkey, dval, maxdeg, order_mode, top);
+}
 
 // single-seed SpMV order: phase (ITEM rows first) then in-degree descending
-__global__ __launch_bounds__(256) void k_order_keys_phase(int32_t n, const int64_t *__restrict__ in_ptr,
-                                                          const uint8_t *__restrict__ node_type,
-                                                          uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval,
-                                                          uint32_t top, int top_bits)
+__device__ __forceinline__ void order_keys_phase_body(int32_t i, int32_t n, const int64_t *__restrict__ in_ptr,
+                                                      const uint8_t *__restrict__ node_type, uint32_t *__restrict__ dkey,
+                                                      uint32_t *__restrict__ dval, uint32_t top, int top_bits)
 {
-    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t deg = (uint32_t)(in_ptr[i + 1] - in_ptr[i]);
     const uint32_t phase = node_type[i] == RWR_NODE_ITEM ? 0u : 1u;
     dkey[i] = (phase << top_bits) | (deg > top ? 0u : top - deg);   // (top_bits <= 31: the phase bit stays inside the key)
     dval[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void k_order_keys_phase(int32_t n, const int64_t *__restrict__ in_ptr,
+                                                          const uint8_t *__restrict__ node_type,
+                                                          uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval,
+                                                          uint32_t top, int top_bits)
+{
+    order_keys_phase_body(blockIdx.x * blockDim.x + threadIdx.x, n, in_ptr, node_type, dkey, dval, top, top_bits);
 }
 
 // items by id descending: ascending sort of ~orderable(id) over the ITEM rows only (every 64-bit key value is a
@@ -287,6 +378,158 @@ __global__ __launch_bounds__(256) void k_stage_out(int32_t n, const int64_t *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Ego-network-sized graphs (n <= STAGE_MAX_N, m <= STAGE_MAX_M): the WHOLE device-side build -- unpack the staging copy,
+// Graph.buildGraph's row pass, the stable transpose, the processing orders, the read-back into pinned memory -- as ONE launch
+// of one 1024-thread workgroup, with workgroup barriers where the general build has 18 kernel boundaries.  The reference
+// rebuilds such a graph per fold and methodology (Experiment.cs:69-105); its build was launch-bound: 18 dependent launches
+// of a few microseconds of work each cost ~270 us, the work itself ~60.  Same element-wise bodies, same sorts, same order of
+// operations per element as the general path (k_row_prepare, k_in_ptr, k_gather_in, k_order_keys*, k_item_*): bit-identical
+// arrays (tests/test_gpu_parity.py: test_build_graph_bitwise, the golden fixtures, the hypothesis graphs, incremental rebuilds).
+struct BuildSmallArgs {
+    int32_t n, n_items, first, do_stage_in;
+    int64_t m;
+    const uint8_t *stage; StageLayout L;
+    int64_t *node_id; uint8_t *node_type; int64_t *rowptr; int32_t *dst; uint8_t *etype; double *w_raw;
+    double *w_norm; int32_t *esrc; uint32_t *skey, *skey2, *sval, *sval2; uint8_t *dangling; double *w_src; int *flags;
+    int64_t *in_ptr; int32_t *in_src; double *in_w;
+    int32_t *row_order, *row_order_x, *item_rows, *item_order;
+    uint64_t *ikey, *ikey2; uint32_t *ival, *ival2;
+    int order_mode; uint32_t top; int top_bits; uint32_t ptop; int ptop_bits; int n_bits; uint64_t id_key_top; int id_key_bits;
+    uint8_t *pin_out;
+    unsigned long long *stamps;      // experiments build: s_memrealtime (100 MHz) at the stage boundaries; nullptr otherwise
+};
+#ifdef RWR_EXPERIMENTS
+#define BS_STAMP(I) { if (a.stamps && tid == 0) a.stamps[(I)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define BS_STAMP(I)
+#endif
+constexpr int BS_CAP = 1024;                     // links per LDS tile and wave of the row pass
+constexpr int BS_ROW_WAVES = 8;                  // waves that take part in the row pass (their tiles share the LDS with the sort's tables)
+__global__ __launch_bounds__(SMALL_SORT_THREADS) void k_build_small(BuildSmallArgs a)
+{
+    constexpr int NT = SMALL_SORT_THREADS;
+    __shared__ SmallSortLds sortlds;
+    __shared__ double sw_all[BS_ROW_WAVES][BS_CAP];
+    __shared__ uint8_t st_all[BS_ROW_WAVES][BS_CAP];
+    __shared__ int64_t srp_all[BS_ROW_WAVES][WAVE + 1];
+    __shared__ double ssum_all[BS_ROW_WAVES][WAVE];
+    const int tid = threadIdx.x, wave = tid / WAVE, lane = tid & (WAVE - 1);
+    const int32_t n = a.n;
+    const int64_t m = a.m;
+    BS_STAMP(0)
+    // ---- the staging copy's arrays (first build only; an incremental rebuild patches the resident arrays)
+    if (a.do_stage_in) {
+        const int64_t work = (m > (int64_t)n + 1) ? m : (int64_t)n + 1;
+        for (int64_t i = tid; i < work; i += NT) {
+            if (i < n) {
+                a.node_id[i] = reinterpret_cast<const int64_t *>(a.stage + a.L.id)[i];
+                a.node_type[i] = a.stage[a.L.nt + i];
+            }
+            if (i <= n) a.rowptr[i] = reinterpret_cast<const int64_t *>(a.stage + a.L.rp)[i];
+            if (i < m) {
+                a.w_raw[i] = reinterpret_cast<const double *>(a.stage + a.L.w)[i];
+                a.dst[i] = reinterpret_cast<const int32_t *>(a.stage + a.L.dst)[i];
+                a.etype[i] = a.stage[a.L.et + i];
+            }
+        }
+        __syncthreads();
+    }
+    BS_STAMP(1)
+    // ---- Graph.buildGraph: filter, list-order row sums, divide (Graph.cs:51-88); 64 rows per wave
+    if (wave < BS_ROW_WAVES)
+        for (int64_t r0 = (int64_t)wave * WAVE; r0 < n; r0 += (int64_t)BS_ROW_WAVES * WAVE)
+            row_prepare_body<BS_CAP>(r0, lane, sw_all[wave], st_all[wave], srp_all[wave], ssum_all[wave], n, a.rowptr, a.dst, a.etype,
+                                     a.w_raw, a.w_norm, a.esrc, a.skey, a.sval, a.dangling, a.w_src, a.flags);
+    __syncthreads();
+    BS_STAMP(2)
+    // ---- stable sort of the raw links by target (UNDEFINED links carry the sentinel key n and go last)
+    const uint32_t *k_sorted = a.skey, *v_sorted = a.sval;
+    if (m > 0) {
+        sort_small_body<uint32_t>(sortlds, a.skey, a.skey2, a.sval, a.sval2, (uint32_t)m, a.n_bits);
+        if (((a.n_bits + 7) / 8) & 1) { k_sorted = a.skey2; v_sorted = a.sval2; }
+    }
+    __syncthreads();
+    BS_STAMP(3)
+    for (int64_t p = tid; p <= m; p += NT) in_ptr_body(p, k_sorted, m, n, a.in_ptr);
+    __syncthreads();
+    const int64_t nnz = a.in_ptr[n];
+    for (int64_t p = tid; p < nnz; p += NT) {
+        const uint32_t e = v_sorted[p];
+        a.in_src[p] = a.esrc[e];
+        a.in_w[p] = a.w_norm[e];
+    }
+    __syncthreads();
+    BS_STAMP(4)
+    // ---- destination-row processing orders.  Same permutations as the general build's two sorts -- (top - deg) ascending,
+    // stable, for any bound `top` of the in-degrees; (phase, top - deg) ascending, stable -- in fewer radix passes: the first
+    // keyed on the graph's own largest in-degree (one 8-bit pass for most ego networks instead of two), the second as ONE
+    // stable pass on the phase bit over the first one's result (LSD order: least significant key first).
+    for (int32_t i = tid; i < n; i += NT) atomicMax(a.flags + 2, (int)(a.in_ptr[i + 1] - a.in_ptr[i]));
+    __syncthreads();
+    const uint32_t maxdeg = (uint32_t)__hip_atomic_load(a.flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int32_t i = tid; i < n; i += NT) {
+        const uint32_t deg = (uint32_t)(a.in_ptr[i + 1] - a.in_ptr[i]);
+        a.skey[i] = (a.order_mode == 1) ? 0u : (a.order_mode == 2) ? (uint32_t)__clz((int)deg) : (maxdeg - deg);
+        a.sval[i] = (uint32_t)i;
+    }
+    __syncthreads();
+    {
+        int bits = 1;
+        while (bits < 32 && (maxdeg >> bits)) ++bits;
+        if (a.order_mode != 0) bits = 8;
+        sort_small_body<uint32_t>(sortlds, a.skey, a.skey2, a.sval, a.sval2, (uint32_t)n, bits);
+        const uint32_t *res = (((bits + 7) / 8) & 1) ? a.sval2 : a.sval;
+        for (int32_t i = tid; i < n; i += NT) a.row_order[i] = (int32_t)res[i];
+    }
+    __syncthreads();
+    for (int32_t q = tid; q < n; q += NT) {
+        const int32_t i = a.row_order[q];
+        a.skey[q] = a.node_type[i] == RWR_NODE_ITEM ? 0u : 1u;
+        a.sval[q] = (uint32_t)i;
+    }
+    __syncthreads();
+    sort_small_body<uint32_t>(sortlds, a.skey, a.skey2, a.sval, a.sval2, (uint32_t)n, 1);
+    for (int32_t i = tid; i < n; i += NT) a.row_order_x[i] = (int32_t)a.sval2[i];       // (one pass: the alternate buffer)
+    __syncthreads();
+    BS_STAMP(5)
+    if (a.first) {   // (the node arrays never change: an incremental rebuild keeps both item orders)
+        for (int32_t i = tid; i < n; i += NT) {
+            a.skey[i] = (a.node_type[i] == RWR_NODE_ITEM) ? 0u : 1u;
+            a.sval[i] = (uint32_t)i;
+        }
+        __syncthreads();
+        sort_small_body<uint32_t>(sortlds, a.skey, a.skey2, a.sval, a.sval2, (uint32_t)n, 8);
+        for (int32_t i = tid; i < a.n_items; i += NT) a.item_rows[i] = (int32_t)a.sval2[i];    // (one pass: the result is in the alternate buffer)
+        __syncthreads();
+        if (a.n_items > 0) {
+            for (int32_t q = tid; q < a.n_items; q += NT) {
+                const int32_t i = a.item_rows[q];
+                a.ikey[q] = a.id_key_top - i64_orderable(a.node_id[i]);
+                a.ival[q] = (uint32_t)i;
+            }
+            __syncthreads();
+            sort_small_body<uint64_t>(sortlds, a.ikey, a.ikey2, a.ival, a.ival2, (uint32_t)a.n_items, a.id_key_bits);
+            const uint32_t *res = (((a.id_key_bits + 7) / 8) & 1) ? a.ival2 : a.ival;
+            for (int32_t q = tid; q < a.n_items; q += NT) a.item_order[q] = (int32_t)res[q];
+        }
+        __syncthreads();
+    }
+    BS_STAMP(6)
+    // ---- what the host needs, straight into pinned memory: link count, flags, in_ptr, dangling
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        reinterpret_cast<int64_t *>(a.pin_out)[0] = a.in_ptr[n];
+        for (int q = 0; q < 4; ++q) reinterpret_cast<int *>(a.pin_out + 8)[q] = a.flags[q];
+    }
+    for (int64_t i = tid; i <= n; i += NT) {
+        reinterpret_cast<int64_t *>(a.pin_out + 32)[i] = a.in_ptr[i];
+        if (i < n) (a.pin_out + 32 + 8 * ((size_t)n + 1))[i] = a.dangling[i];
+    }
+    BS_STAMP(7)
+}
+
 static int bit_length(uint64_t v)
 {
     int b = 0;
@@ -367,10 +610,7 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
         }
         RWR_TRY(g->d_stage.ensure(L.total + 8));
         RWR_HIP(hipMemcpyAsync(g->d_stage.p, st, L.total, hipMemcpyHostToDevice, s));
-        const int64_t work = (m > (int64_t)n + 1) ? m : (int64_t)n + 1;
-        hipLaunchKernelGGL(k_stage_in, dim3(cdiv((size_t)work, 256)), dim3(256), 0, s, n, m, g->d_stage.p, L, g->node_id.p,
-                           g->node_type.p, g->rowptr.p, g->dst.p, g->etype.p, g->w_raw.p);
-        RWR_HIP(hipGetLastError());
+        g->stage_pending = 1;           // (k_build_small unpacks the copy: graph_derive)
     } else {
         RWR_HIP(hipMemcpyAsync(g->node_id.p, node_id, sizeof(int64_t) * n, hipMemcpyHostToDevice, s));
         RWR_HIP(hipMemcpyAsync(g->node_type.p, node_type, (size_t)n, hipMemcpyHostToDevice, s));
@@ -421,6 +661,40 @@ int32_t graph_update_links(rwr_graph *g, int64_t count, const int64_t *idx, cons
     return graph_derive(g, false);
 }
 
+// host side of a finished build: bins of the in-degree orders, statistics
+static int32_t derive_finish(rwr_graph *g, const int *h_flags, hipEvent_t e0, hipEvent_t e1)
+{
+    const int32_t n = g->n;
+    double bt_t = bt_now();
+    g->max_in_deg = h_flags[2];
+    g->bin_end[0] = g->bin_end[1] = g->bin_end[2] = g->bin_huge = g->bin_hub = 0;
+    static const int hub_t_env = [] { const char *e = getenv("RWR_HUB_T"); return e ? atoi(e) : 2048; }();   // (measured best on the MovieLens-shaped graph: 2048 / prefix 256)
+    g->hub_t = hub_t_env < 128 ? 128 : hub_t_env;   // (hub rows are a prefix of the wave-per-row bin: >= 128 in-links)
+    for (int ph = 0; ph < 2; ++ph) g->x_rows[ph] = g->x_hub[ph] = g->x_bins[ph][0] = g->x_bins[ph][1] = g->x_bins[ph][2] = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        const int64_t deg = g->h_in_ptr[i + 1] - g->h_in_ptr[i];
+        g->bin_huge += deg >= 2048;
+        g->bin_hub += deg >= g->hub_t;
+        g->bin_end[0] += deg >= 128;
+        g->bin_end[1] += deg >= 32;
+        g->bin_end[2] += deg >= 4;
+        const int ph = g->h_is_item[i] ? 0 : 1;
+        g->x_rows[ph] += 1;
+        g->x_hub[ph] += deg >= g->hub_t;
+        g->x_bins[ph][0] += deg >= 128;
+        g->x_bins[ph][1] += deg >= 32;
+        g->x_bins[ph][2] += deg >= 4;
+    }
+    BT("D2H in_ptr/dangling + bins");
+    float ms = 0.f;
+    RWR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    g->stats.build_ms = ms;
+    g->stats.nnz = g->nnz;
+    g->stats.uniform = g->uniform;
+    g->stats.uniform_path = g->vf;
+    return RWR_OK;
+}
+
 // Graph.buildGraph + transpose + processing orders, from the device-resident raw lists
 static int32_t graph_derive(rwr_graph *g, bool first)
 {
@@ -458,6 +732,87 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     hipEvent_t e0 = g->ev_a, e1 = g->ev_b;
     RWR_HIP(hipEventRecord(e0, s));
 
+    const char *om_s = RWR_TUNE_ENV("RWR_ROW_ORDER");
+    const bool fused = g->staged && g->sm_stage && n <= STAGE_MAX_N && m <= STAGE_MAX_M && (!om_s || atoi(om_s) == 0);
+    if (fused) {
+        // ego-network-sized graph: the whole device-side build is ONE launch (k_build_small) and one synchronisation
+        static const int vf_env_s = [] { const char *e = getenv("RWR_VALUE_FREE"); return e ? atoi(e) : 1; }();
+        DevBuf<uint64_t> ikey_s, ikey2_s;
+        DevBuf<uint32_t> ival_s, ival2_s;
+        RWR_TRY(ikey_s.alloc(n));
+        RWR_TRY(ikey2_s.alloc(n));
+        RWR_TRY(ival_s.alloc(n));
+        RWR_TRY(ival2_s.alloc(n));
+        RWR_TRY(g->in_src.ensure((size_t)m + 64));
+        RWR_TRY(g->in_w.ensure((size_t)(m > 0 ? m : 1)));
+        uint8_t *pin = static_cast<uint8_t *>(g->sm_stage) + STAGE_OUT_OFF;
+        BuildSmallArgs a{};
+        a.n = n; a.n_items = n_items; a.first = first ? 1 : 0; a.do_stage_in = g->stage_pending ? 1 : 0; a.m = m;
+        a.stage = g->d_stage.p; a.L = stage_layout(n, m);
+        a.node_id = g->node_id.p; a.node_type = g->node_type.p; a.rowptr = g->rowptr.p; a.dst = g->dst.p; a.etype = g->etype.p;
+        a.w_raw = g->w_raw.p; a.w_norm = g->w_norm_raw.p; a.esrc = esrc.p; a.skey = skey.p; a.skey2 = skey2.p; a.sval = sval.p;
+        a.sval2 = sval2.p; a.dangling = g->dangling.p; a.w_src = g->w_src.p; a.flags = flags.p; a.in_ptr = g->in_ptr.p;
+        a.in_src = g->in_src.p; a.in_w = g->in_w.p; a.row_order = g->row_order.p; a.row_order_x = g->row_order_x.p;
+        a.item_rows = g->item_rows.p; a.item_order = g->item_order.p; a.ikey = ikey_s.p; a.ikey2 = ikey2_s.p; a.ival = ival_s.p;
+        a.ival2 = ival2_s.p;
+        a.order_mode = 0;
+        a.top = (uint32_t)m;                                   // (any bound of the in-degrees gives the same order)
+        a.top_bits = bit_length((uint64_t)m) > 0 ? bit_length((uint64_t)m) : 1;
+        a.ptop_bits = a.top_bits > 31 ? 31 : a.top_bits;
+        a.ptop = a.top_bits > 31 ? 0x7FFFFFFFu : a.top;
+        a.n_bits = bit_length((uint64_t)n);
+        a.id_key_top = g->id_key_top; a.id_key_bits = g->id_key_bits;
+        a.pin_out = pin;
+        a.stamps = nullptr;
+#ifdef RWR_EXPERIMENTS
+        DevBuf<unsigned long long> stamps_d;
+        if (bt_on) { RWR_TRY(stamps_d.alloc(8)); a.stamps = stamps_d.p; }
+#endif
+        hipLaunchKernelGGL(k_build_small, dim3(1), dim3(SMALL_SORT_THREADS), 0, s, a);
+        RWR_HIP(hipGetLastError());
+        g->stage_pending = 0;
+        RWR_HIP(hipEventRecord(e1, s));
+        BT("enqueue one-launch build");
+        g->h_in_ptr.resize((size_t)n + 1);
+        g->h_dangling.resize((size_t)n);
+        RWR_HIP(hipStreamSynchronize(s));                      // the ONE synchronisation of an ego-network-sized build
+        const int64_t nnz_s = reinterpret_cast<const int64_t *>(pin)[0];
+        memcpy(h_flags, pin + 8, sizeof(h_flags));
+        memcpy(g->h_in_ptr.data(), pin + 32, sizeof(int64_t) * ((size_t)n + 1));
+        memcpy(g->h_dangling.data(), pin + 32 + 8 * ((size_t)n + 1), (size_t)n);
+        BT("sync (whole build)");
+#ifdef RWR_EXPERIMENTS
+        if (bt_on) {
+            unsigned long long hs[8];
+            RWR_HIP(hipMemcpy(hs, stamps_d.p, sizeof(hs), hipMemcpyDeviceToHost));
+            unsigned long long rp[16];
+            (void)hipMemcpyFromSymbol(rp, HIP_SYMBOL(rp_dbg), sizeof(rp));
+            fprintf(stderr, "[build] row pass of group 0 (us): setup %.1f sweep1 %.1f sweep2 %.1f; started %.1f after stage 1\n", (rp[1] - rp[0]) / 100.0,
+                    (rp[2] - rp[1]) / 100.0, (rp[3] - rp[2]) / 100.0, (rp[0] - hs[1]) / 100.0);
+            fprintf(stderr, "[build] k_build_small stages (us): unpack %.1f rows %.1f linksort %.1f in_ptr+gather %.1f orders %.1f items %.1f out %.1f\n",
+                    (hs[1] - hs[0]) / 100.0, (hs[2] - hs[1]) / 100.0, (hs[3] - hs[2]) / 100.0, (hs[4] - hs[3]) / 100.0, (hs[5] - hs[4]) / 100.0,
+                    (hs[6] - hs[5]) / 100.0, (hs[7] - hs[6]) / 100.0);
+        }
+#endif
+        if (h_flags[1]) {
+            set_error("rwr_graph_create: a link targets a node outside [0, %d)", n);
+            return RWR_E_RANGE;
+        }
+        g->nnz = nnz_s;
+        g->uniform = h_flags[0] ? 0 : 1;
+        g->nonneg = h_flags[3] ? 0 : 1;
+        g->vf = (g->uniform && g->nonneg && vf_env_s) ? 1 : 0;   // (in_w stays: small.hip reads it)
+        return derive_finish(g, h_flags, e0, e1);
+    }
+    if (g->stage_pending) {   // (staged upload, general build: unpack the copy by its own kernel)
+        const StageLayout L = stage_layout(n, m);
+        const int64_t work = (m > (int64_t)n + 1) ? m : (int64_t)n + 1;
+        hipLaunchKernelGGL(k_stage_in, dim3(cdiv((size_t)work, 256)), dim3(256), 0, s, n, m, g->d_stage.p, L, g->node_id.p,
+                           g->node_type.p, g->rowptr.p, g->dst.p, g->etype.p, g->w_raw.p);
+        RWR_HIP(hipGetLastError());
+        g->stage_pending = 0;
+    }
+
     hipLaunchKernelGGL(k_row_prepare, dim3(cdiv(n, RP_WPB * WAVE)), dim3(RP_WPB * WAVE), 0, s, n, g->rowptr.p, g->dst.p, g->etype.p,
                        g->w_raw.p, g->w_norm_raw.p, esrc.p, skey.p, sval.p, g->dangling.p, g->w_src.p, flags.p);
     RWR_HIP(hipGetLastError());
@@ -473,35 +828,46 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     int64_t nnz = 0;
     const bool staged = g->staged && g->sm_stage;
     uint8_t *pin_out = staged ? static_cast<uint8_t *>(g->sm_stage) + STAGE_OUT_OFF : nullptr;
+    static const int vf_env = [] { const char *e = getenv("RWR_VALUE_FREE"); return e ? atoi(e) : 1; }();
+    int64_t nnz_bound = 0;          // what the launches below are sized for
     if (staged) {
-        hipLaunchKernelGGL(k_stage_out, dim3(1), dim3(256), 0, s, n, g->in_ptr.p, flags.p, g->dangling.p, pin_out, 0);
+        // ego-network-sized graph: NO host round trip here.  The number of explicit links (<= m) stays on the device, the
+        // in-lists are sized for m, the per-entry weights are always built (such graphs carry MENTION weights, and the
+        // one-launch kernel of small.hip reads them anyway), and the checks wait for the one synchronisation at the end:
+        // a link with a bad target was keyed to the sentinel row and is harmless until then.  (The mid-way synchronisation
+        // cost ~45 us of host round trip and left the second half of the pipeline un-enqueued meanwhile.)
+        nnz_bound = m;
+        RWR_TRY(g->in_src.ensure((size_t)m + 64));
+        RWR_TRY(g->in_w.ensure((size_t)(m > 0 ? m : 1)));
+        if (m > 0) {
+            hipLaunchKernelGGL(k_gather_in, dim3(cdiv((size_t)m, 256)), dim3(256), 0, s, v_sorted, m, esrc.p, g->w_norm_raw.p,
+                               g->in_src.p, g->in_w.p, g->in_ptr.p + n);
+            RWR_HIP(hipGetLastError());
+        }
+        BT("enqueue row pass + link sort + gather");
     } else {
         RWR_HIP(hipMemcpyAsync(&nnz, g->in_ptr.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         RWR_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
-    }
-    BT("enqueue row pass + link sort");
-    RWR_HIP(hipStreamSynchronize(s));
-    if (staged) {
-        nnz = reinterpret_cast<const int64_t *>(pin_out)[0];
-        memcpy(h_flags, pin_out + 8, sizeof(h_flags));
-    }
-    BT("sync 1 (H2D + row pass + sort)");
-    if (h_flags[1]) {
-        set_error("rwr_graph_create: a link targets a node outside [0, %d)", n);
-        return RWR_E_RANGE;
-    }
-    g->nnz = nnz;
-    g->uniform = h_flags[0] ? 0 : 1;
-    g->nonneg = h_flags[3] ? 0 : 1;
-    static const int vf_env = [] { const char *e = getenv("RWR_VALUE_FREE"); return e ? atoi(e) : 1; }();
-    g->vf = (g->uniform && g->nonneg && vf_env) ? 1 : 0;
-    RWR_TRY(g->in_src.ensure((size_t)nnz + 64));   // (padded: wide index loads may run past a row's end)
-    if (g->vf) g->in_w.release();
-    else RWR_TRY(g->in_w.ensure((size_t)nnz));
-    if (nnz > 0) {
-        hipLaunchKernelGGL(k_gather_in, dim3(cdiv((size_t)nnz, 256)), dim3(256), 0, s, v_sorted, nnz, esrc.p,
-                           g->w_norm_raw.p, g->in_src.p, g->vf ? (double *)nullptr : g->in_w.p);
-        RWR_HIP(hipGetLastError());
+        BT("enqueue row pass + link sort");
+        RWR_HIP(hipStreamSynchronize(s));
+        BT("sync 1 (H2D + row pass + sort)");
+        if (h_flags[1]) {
+            set_error("rwr_graph_create: a link targets a node outside [0, %d)", n);
+            return RWR_E_RANGE;
+        }
+        g->nnz = nnz;
+        g->uniform = h_flags[0] ? 0 : 1;
+        g->nonneg = h_flags[3] ? 0 : 1;
+        g->vf = (g->uniform && g->nonneg && vf_env) ? 1 : 0;
+        nnz_bound = nnz;
+        RWR_TRY(g->in_src.ensure((size_t)nnz + 64));   // (padded: wide index loads may run past a row's end)
+        if (g->vf) g->in_w.release();
+        else RWR_TRY(g->in_w.ensure((size_t)nnz));
+        if (nnz > 0) {
+            hipLaunchKernelGGL(k_gather_in, dim3(cdiv((size_t)nnz, 256)), dim3(256), 0, s, v_sorted, nnz, esrc.p,
+                               g->w_norm_raw.p, g->in_src.p, g->vf ? (double *)nullptr : g->in_w.p);
+            RWR_HIP(hipGetLastError());
+        }
     }
 
     // destination-row processing order (in-degree descending) and ITEM rows by id descending
@@ -513,9 +879,10 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     RWR_TRY(ikey2.alloc(n));
     RWR_TRY(ival.alloc(n));
     RWR_TRY(ival2.alloc(n));
-    // (every in-degree is <= the number of explicit links: `top - deg` keys need bit_length(nnz) bits, not 32)
-    const uint32_t top = (uint32_t)nnz;
-    const int top_bits = bit_length((uint64_t)nnz) > 0 ? bit_length((uint64_t)nnz) : 1;
+    // (every in-degree is <= the number of explicit links: `top - deg` keys need bit_length(nnz) bits, not 32; any bound of
+    //  the in-degrees gives the same order)
+    const uint32_t top = (uint32_t)nnz_bound;
+    const int top_bits = bit_length((uint64_t)nnz_bound) > 0 ? bit_length((uint64_t)nnz_bound) : 1;
     hipLaunchKernelGGL(k_order_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, n, g->in_ptr.p, g->node_type.p,
                        g->node_id.p, skey.p, sval.p, flags.p + 2, order_mode, top);
     RWR_HIP(hipGetLastError());
@@ -553,11 +920,20 @@ static int32_t graph_derive(rwr_graph *g, bool first)
                            pin_out, 1);
         RWR_HIP(hipEventRecord(e1, s));
         BT("enqueue gather + orders");
-        RWR_HIP(hipStreamSynchronize(s));
+        RWR_HIP(hipStreamSynchronize(s));                   // the ONE synchronisation of an ego-network-sized build
+        nnz = reinterpret_cast<const int64_t *>(pin_out)[0];
         memcpy(h_flags, pin_out + 8, sizeof(h_flags));
         memcpy(g->h_in_ptr.data(), pin_out + 32, sizeof(int64_t) * ((size_t)n + 1));
         memcpy(g->h_dangling.data(), pin_out + 32 + 8 * ((size_t)n + 1), (size_t)n);
-        BT("sync 2 (orders)");
+        BT("sync (whole build)");
+        if (h_flags[1]) {
+            set_error("rwr_graph_create: a link targets a node outside [0, %d)", n);
+            return RWR_E_RANGE;
+        }
+        g->nnz = nnz;
+        g->uniform = h_flags[0] ? 0 : 1;
+        g->nonneg = h_flags[3] ? 0 : 1;
+        g->vf = (g->uniform && g->nonneg && vf_env) ? 1 : 0;   // (in_w stays: see above)
     } else {
         RWR_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
         RWR_HIP(hipEventRecord(e1, s));
@@ -567,33 +943,7 @@ static int32_t graph_derive(rwr_graph *g, bool first)
         RWR_HIP(hipMemcpy(g->h_in_ptr.data(), g->in_ptr.p, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost));
         RWR_HIP(hipMemcpy(g->h_dangling.data(), g->dangling.p, (size_t)n, hipMemcpyDeviceToHost));
     }
-    g->max_in_deg = h_flags[2];
-    g->bin_end[0] = g->bin_end[1] = g->bin_end[2] = g->bin_huge = g->bin_hub = 0;
-    static const int hub_t_env = [] { const char *e = getenv("RWR_HUB_T"); return e ? atoi(e) : 2048; }();   // (measured best on the MovieLens-shaped graph: 2048 / prefix 256)
-    g->hub_t = hub_t_env < 128 ? 128 : hub_t_env;   // (hub rows are a prefix of the wave-per-row bin: >= 128 in-links)
-    for (int ph = 0; ph < 2; ++ph) g->x_rows[ph] = g->x_hub[ph] = g->x_bins[ph][0] = g->x_bins[ph][1] = g->x_bins[ph][2] = 0;
-    for (int32_t i = 0; i < n; ++i) {
-        const int64_t deg = g->h_in_ptr[i + 1] - g->h_in_ptr[i];
-        g->bin_huge += deg >= 2048;
-        g->bin_hub += deg >= g->hub_t;
-        g->bin_end[0] += deg >= 128;
-        g->bin_end[1] += deg >= 32;
-        g->bin_end[2] += deg >= 4;
-        const int ph = g->h_is_item[i] ? 0 : 1;
-        g->x_rows[ph] += 1;
-        g->x_hub[ph] += deg >= g->hub_t;
-        g->x_bins[ph][0] += deg >= 128;
-        g->x_bins[ph][1] += deg >= 32;
-        g->x_bins[ph][2] += deg >= 4;
-    }
-    BT("D2H in_ptr/dangling + bins");
-    float ms = 0.f;
-    RWR_HIP(hipEventElapsedTime(&ms, e0, e1));
-    g->stats.build_ms = ms;
-    g->stats.nnz = g->nnz;
-    g->stats.uniform = g->uniform;
-    g->stats.uniform_path = g->vf;
-    return RWR_OK;
+    return derive_finish(g, h_flags, e0, e1);
 }
 
 int32_t ensure_in_w(rwr_graph *g)

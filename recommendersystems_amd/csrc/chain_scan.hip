@@ -370,13 +370,16 @@ __global__ __launch_bounds__(64) void k_cs_carry(int32_t n, int nchunks, const u
         F1 = d1[i__];                                                \
     }
     int c = 0;
+    int done = 0;                                         // blocks [c, c + done) of the window are already carried
     CS_LOAD(0, ap, ep, f0, f1)
     while (c < nchunks) {
-        if (c + WAVE < nchunks) CS_LOAD(c + WAVE, apn, epn, f0n, f1n)   // the next window, should this one be accepted whole
+        // the next window is requested once, when this one is entered (a redone block does NOT reload the window: the blocks
+        // behind it are composed again from the registers under the new sum -- a reload cost a memory round trip per redo)
+        if (done == 0 && c + WAVE < nchunks) CS_LOAD(c + WAVE, apn, epn, f0n, f1n)
         const unsigned long long b = (unsigned long long)__double_as_longlong(s);
         const int eb = (int)((b >> 52) & 0x7ff);
         const bool normal = eb != 0 && eb != 0x7ff;
-        const bool nz = ap != 0.0;                        // (block sum 0 <=> every addend +0.0: the block is a no-op)
+        const bool nz = ap != 0.0 && lane >= done;        // (block sum 0 <=> every addend +0.0: the block is a no-op)
         PF f{0, 0};
         if (nz) { f.d0 = f0; f.d1 = f1; }
 #pragma unroll
@@ -392,15 +395,20 @@ __global__ __launch_bounds__(64) void k_cs_carry(int32_t n, int nchunks, const u
         if (!bad) {
             if (normal) s = cs_from_m(eb, __shfl(M, WAVE - 1, WAVE));
             c += WAVE;
+            done = 0;
             ap = apn; ep = epn; f0 = f0n; f1 = f1n;
             continue;
         }
         const int L = __builtin_ctzll(bad);
-        if (L > 0 && normal) s = cs_from_m(eb, __shfl(M, L - 1, WAVE));   // the blocks before it
+        if (L > 0 && normal) s = cs_from_m(eb, __shfl(M, L - 1, WAVE));   // the blocks before it (carried ones are identities)
         s = cs_redo_block<G>(s, n, nchunks, c + L, tile, k, dangling, X, seeds, c1, in_ptr, in_src, evoff, evterm, lnk);
         ++redo;
-        c += L + 1;
-        if (c < nchunks) CS_LOAD(c, ap, ep, f0, f1)
+        done = L + 1;
+        if (done >= WAVE || c + done >= nchunks) {        // the window is exhausted
+            c += WAVE;
+            done = 0;
+            ap = apn; ep = epn; f0 = f0n; f1 = f1n;
+        }
     }
 #undef CS_LOAD
     if (lane == 0) {

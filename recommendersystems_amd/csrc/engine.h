@@ -25,6 +25,7 @@ struct rwr_graph {
                              // >= 0, which the zero-skipping frontier paths and the binade scan rely on; otherwise the general kernels run
     int32_t max_in_deg = 0;
     int32_t staged = 0;      // ego-network-sized graph: raw arrays arrived through the pinned staging buffer (build.hip)
+    int32_t stage_pending = 0;   // ... and the device-side copy of that buffer has not been unpacked into the arrays yet
     int32_t poisoned = 0;    // a failed incremental rebuild left raw and derived arrays out of step: every entry point refuses
     // rows of row_order (in-degree descending) with in-degree >= 128 / >= 32 / >= 4: lane-width bins of the K = 1 vector SpMV
     int32_t bin_end[3] = {0, 0, 0};

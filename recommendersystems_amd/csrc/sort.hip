@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "sort_small.h"
 
 namespace rwr {
 
@@ -164,88 +165,13 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_scatter(
 }
 
 // Few elements (an ego network's node arrays, its link list): ALL passes of the sort in ONE launch of one 1024-thread
-// workgroup -- per pass a digit histogram (LDS atomics), its exclusive scan, and the stable scatter tile by tile with the same
-// wave-ballot ranking as k_sort_scatter; workgroup barriers where the general path has three kernel launches per pass.  The
-// graph build of such a graph is launch-bound: this takes ~30 launches out of it.
-constexpr int SMALL_SORT_THREADS = 1024;
-constexpr size_t SMALL_SORT_MAX = 8192;
+// workgroup (sort_small.h).  The graph build of such a graph is launch-bound: this takes ~30 launches out of it.
 template <typename KeyT>
 __global__ __launch_bounds__(SMALL_SORT_THREADS) void k_sort_small(KeyT *ka, KeyT *kb, uint32_t *va, uint32_t *vb, uint32_t m,
                                                                    int key_bits)
 {
-    constexpr int NW = SMALL_SORT_THREADS / WAVE;
-    __shared__ uint32_t run[RADIX];
-    __shared__ uint32_t wcnt[NW][RADIX];
-    __shared__ uint32_t wsum[RADIX / WAVE];
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-    KeyT *kin = ka, *kout = kb;
-    uint32_t *vin = va, *vout = vb;
-    for (int shift = 0; shift < key_bits; shift += 8) {
-        if (tid < RADIX) run[tid] = 0;
-        for (int i = tid; i < NW * RADIX; i += SMALL_SORT_THREADS) (&wcnt[0][0])[i] = 0;
-        __syncthreads();
-        for (uint32_t i = tid; i < m; i += SMALL_SORT_THREADS) atomicAdd(&run[(unsigned)(kin[i] >> shift) & (RADIX - 1)], 1u);
-        __syncthreads();
-        // exclusive scan of the 256 digit counts (waves 0-3)
-        uint32_t v = 0, incl = 0;
-        if (tid < RADIX) {
-            v = run[tid];
-            incl = v;
-#pragma unroll
-            for (int off = 1; off < WAVE; off <<= 1) {
-                const uint32_t o = __shfl_up(incl, off, WAVE);
-                if (lane >= off) incl += o;
-            }
-            if (lane == WAVE - 1) wsum[wv] = incl;
-        }
-        __syncthreads();
-        if (tid < RADIX) {
-            uint32_t pre = 0;
-            for (int q = 0; q < wv; ++q) pre += wsum[q];
-            run[tid] = pre + incl - v;
-        }
-        __syncthreads();
-        // stable scatter, tile by tile in index order
-        for (uint32_t base = 0; base < m; base += SMALL_SORT_THREADS) {
-            const uint32_t idx = base + tid;
-            const bool valid = idx < m;
-            const KeyT key = valid ? kin[idx] : (KeyT)0;
-            const uint32_t val = valid ? vin[idx] : 0u;
-            const unsigned digit = (unsigned)(key >> shift) & (RADIX - 1);
-            unsigned long long peers = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (digit >> b) & 1u;
-                const unsigned long long mb = __ballot(valid && bit);
-                peers &= bit ? mb : ~mb;
-            }
-            const unsigned rank_in_wave = __popcll(peers & ((1ull << lane) - 1ull));
-            if (valid && rank_in_wave == 0) wcnt[wv][digit] = __popcll(peers);
-            __syncthreads();
-            uint32_t pos = 0;
-            if (valid) {
-                pos = run[digit] + rank_in_wave;
-                for (int q = 0; q < wv; ++q) pos += wcnt[q][digit];
-            }
-            __syncthreads();
-            if (tid < RADIX) {
-                uint32_t sacc = 0;
-#pragma unroll
-                for (int q = 0; q < NW; ++q) {
-                    sacc += wcnt[q][tid];
-                    wcnt[q][tid] = 0;
-                }
-                run[tid] += sacc;
-            }
-            if (valid) {
-                kout[pos] = key;
-                vout[pos] = val;
-            }
-            __syncthreads();
-        }
-        { KeyT *t = kin; kin = kout; kout = t; }
-        { uint32_t *t = vin; vin = vout; vout = t; }
-    }
+    __shared__ SmallSortLds L;
+    sort_small_body<KeyT>(L, ka, kb, va, vb, m, key_bits);
 }
 
 template <typename KeyT>

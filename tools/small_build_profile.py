@@ -5,7 +5,9 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from recommendersystems_amd import synth                                  # noqa: E402
+from recommendersystems_amd import synth, _lib                            # noqa: E402
+if os.environ.get("RWR_TOOLS_EXP_LIB"):        # the experiments build (make -C recommendersystems_amd/csrc exp): RWR_BUILD_TIMING
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "librwr_exp.so")
 from recommendersystems_amd.rwr_based import Graph, Recommender           # noqa: E402
 
 g = synth.bipartite(9, 60, 2000, 4000)
