@@ -167,6 +167,10 @@ __global__ __launch_bounds__(256) void k_sw_fill(int32_t n_sw, int32_t ns, int n
 // gathers, then 16 dependent adds); a group that holds a piece end is walked word-row by word-row, switching accumulator
 // at a slot end and refilling LDS at a block end.
 constexpr int SW_D = 16;          // word-rows in flight per wave (8 KB)
+#ifndef RWR_SW_AUX
+#define RWR_SW_AUX 0
+#endif
+constexpr int SW_STREAM_AUX = RWR_SW_AUX;   // cache policy of the stream's loads (2 = nt: read once, do not displace z in the L2s)
 constexpr int SW_G = 4;           // word-rows per group
 
 #ifdef RWR_SWEEP_STAMPS   // compile-time option of the experiments build: per-wave cycle counts (tools/sweep_stamps.py)
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(512) void k_sweep_lds(int32_t n, int32_t n_sw, int 
     const int lane8 = lane * 8;
     v2u_t r[SW_D];
 #pragma unroll
-    for (int u = 0; u < SW_D; ++u) r[u] = __builtin_amdgcn_raw_buffer_load_b64(srs, lane8, (int)(u * (WAVE * 8u)), 0);
+    for (int u = 0; u < SW_D; ++u) r[u] = __builtin_amdgcn_raw_buffer_load_b64(srs, lane8, (int)(u * (WAVE * 8u)), SW_STREAM_AUX);
 
     int b = 0, i = 0;
     const double *zc = zs;
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(512) void k_sweep_lds(int32_t n, int32_t n_sw, int 
             }                                                                                                             \
         }                                                                                                                 \
         _Pragma("unroll") for (int u = 0; u < SW_G; ++u)                                                                  \
-            r[(GQ) * SW_G + u] = __builtin_amdgcn_raw_buffer_load_b64(srs, lane8, (int)((t0 + SW_D + u) * (WAVE * 8u)), 0); \
+            r[(GQ) * SW_G + u] = __builtin_amdgcn_raw_buffer_load_b64(srs, lane8, (int)((t0 + SW_D + u) * (WAVE * 8u)), SW_STREAM_AUX); \
     }
     static_assert((SW_D / SW_G) % 2 == 0, "the group buffers alternate");
     for (uint32_t t = 0; t < T; t += SW_D) {

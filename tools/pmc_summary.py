@@ -17,7 +17,7 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     return name.split("(")[0]
 
 
