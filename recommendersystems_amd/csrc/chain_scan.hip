@@ -419,6 +419,343 @@ __global__ __launch_bounds__(64) void k_cs_carry(int32_t n, int nchunks, const u
     }
 }
 
+// ---------------------------------------------------------------------------------------------- single seed (G = 1)
+// A single-seed step WAITS for the chain (the SpMV beside it takes 110-180 us on the 0.2-0.6 M-node graphs), and the chain
+// waited for the carry's redone blocks: the sum doubles ~20 times on its way from the first rank to d, ~12 of those
+// crossings lie in block 0 and the others in one block each, and one wave redoing a 1024-row block costs 8-9 us (three or
+// four dependent memory round trips by a lone wave, then two passes of 16 pf_of per lane) -- 100 of the carry's 128 us.
+// The parallel pass can do nearly all of it ahead of time, because WHERE the sum leaves its binade is predictable:
+//   * block 0 (more generally the first block holding a non-zero addend) starts from exactly +0.0, so its workgroup adds it
+//     up sequentially -- literally the reference's loop -- and hands the carry the exact sum behind it         (CS_EXACT);
+//   * a block whose approximate incoming and outgoing sums lie in adjacent binades e, e + 1 is SPLIT: the approximate
+//     incoming mantissa locates the 4-row run in which the sum crosses; the block hands over the composed function of
+//     the runs before it (under e), the run's four addends, and the composed function of the runs behind it (under
+//     e + 1).  The carry applies function, four real adds, function -- and CHECKS each part (sum still inside e before
+//     the run, inside e + 1 after the four adds and at the block's end).  A row's addend is ~10^10 ulps of the sum while
+//     the approximate prefix is good to ~10^3, so the run is the right one except with probability ~10^-7; then, as for
+//     any failed check, the block is redone exactly by the carry wave (cs_redo_block)                           (CS_SPLIT);
+//   * anything else -- two crossings in a block behind the first, a link into the seed inside the split run, a subnormal
+//     incoming sum -- is left to the carry's redo                                                               (CS_REDO).
+// The prediction (k_cs_plan) is folded into the block kernel: every workgroup sums the approximate block sums in front of it.
+constexpr int CS_PLAIN = 0, CS_SPLIT = 1, CS_EXACT = 2, CS_REDO = 3;
+constexpr int CS_KIND_SHIFT = 12;                       // cs_e cell: predicted exponent | kind << 12
+constexpr int CS_SIDE_WORDS = 8;                        // a[0..3], after.d0, after.d1, exact, (spare)
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const uint8_t *__restrict__ dangling,
+                                                   const double *__restrict__ X, const int32_t *__restrict__ seeds, double c1,
+                                                   const int64_t *__restrict__ in_ptr, const int32_t *__restrict__ in_src,
+                                                   const int64_t *__restrict__ evoff, const double *__restrict__ evterm,
+                                                   const int32_t *__restrict__ lnk, const double *__restrict__ approx,
+                                                   int32_t *__restrict__ ek, long long *__restrict__ od0,
+                                                   long long *__restrict__ od1, double *__restrict__ side)
+{
+    constexpr int CH = CsGeom<1>::CH, CS_R = CsGeom<1>::R;      // 1024 rows per block, 4 per thread
+    __shared__ double a_s[CH + CH / 16];
+    __shared__ long long r0[256], r1[256];
+    __shared__ long long w0[4], w1[4];
+    __shared__ int rstar;
+    const int c = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const double *x = X + (size_t)slot * (size_t)n;
+    const int32_t s = seeds[slot];
+    const size_t base = (size_t)slot * nchunks, oidx = base + c;
+    // the approximate sum in front of this block (any association will do for a prediction)
+    double pa = 0.0;
+    for (int i = tid; i < c; i += 256) pa += approx[base + i];
+    const double ap = approx[oidx];
+    // this block's addends, staged in LDS
+    const int64_t row0 = (int64_t)c * CH;
+#pragma unroll
+    for (int j = 0; j < CH / 256; ++j) {
+        const int q = tid + 256 * j;
+        const int64_t row = row0 + q;
+        double a = 0.0;
+        if (row < n) {
+            const double xv = x[row];
+            const double rw = c1 * xv;                       // Model.cs:84
+            a = dangling[row] ? xv : (xv - rw);              // Model.cs:97 / :91
+        }
+        a_s[cs_pad(q)] = a;
+    }
+    double *racc = reinterpret_cast<double *>(r0);
+    racc[tid] = pa;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) racc[tid] += racc[tid + st];
+        __syncthreads();
+    }
+    const double pre = racc[0];
+    __syncthreads();                                         // (r0 is reused below)
+    double *sd = side + oidx * CS_SIDE_WORDS;
+    const int epre = (int)(((unsigned long long)__double_as_longlong(pre) >> 52) & 0x7ff);
+    if (ap == 0.0) {                                         // every addend +0.0: a no-op for the carry
+        if (tid == 0) { ek[oidx] = epre | (CS_PLAIN << CS_KIND_SHIFT); od0[oidx] = 0; od1[oidx] = 0; }
+        return;
+    }
+    // this block's share of the seed's in-link list (sorted by source row)
+    int32_t l1 = 0, a0 = 0;
+    const int32_t *srcp = in_src;
+    const double *termp = evterm;
+    if (s >= 0) {
+        const int32_t *lk = lnk + (size_t)slot * (size_t)(nchunks + 1) + c;
+        a0 = lk[0];
+        l1 = lk[1];
+        if (l1 > a0) { srcp = in_src + in_ptr[s]; termp = evterm + evoff[slot]; }
+    }
+    if (pre == 0.0) {
+        // nothing non-zero in front: the sum enters as exactly +0.0 and one thread adds the block up in the reference's order
+        if (tid == 0) {
+            double t = 0.0;
+            int32_t l = a0;
+            for (int u0 = 0; u0 < CH; u0 += 16) {          // 16 rows per batch: one LDS round trip, then the dependent adds
+                double v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = a_s[cs_pad(u0 + k)];
+                if (l < l1 && (int64_t)srcp[l] < row0 + u0 + 16) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        while (l < l1 && (int64_t)srcp[l] == row0 + u0 + k) { t += termp[l]; ++l; }   // Model.cs:85-88
+                        t += v[k];                                                                     // Model.cs:91-93,96-97
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) t += v[k];
+                }
+            }
+            sd[6] = t;
+            ek[oidx] = CS_EXACT << CS_KIND_SHIFT;
+            od0[oidx] = 0;
+            od1[oidx] = 0;
+        }
+        return;
+    }
+    const double post = pre + ap;
+    const int epost = (int)(((unsigned long long)__double_as_longlong(post) >> 52) & 0x7ff);
+    if (epre == 0 || epost >= 0x7ff || epost > epre + 1) {
+        if (tid == 0) { ek[oidx] = epre | (CS_REDO << CS_KIND_SHIFT); od0[oidx] = 0; od1[oidx] = 0; }
+        return;
+    }
+    // first link whose source row is >= this thread's run
+    const int64_t ra = row0 + (int64_t)tid * CS_R;
+    int32_t lb = l1;
+    if (l1 > a0) {
+        int32_t lo = a0, hi = l1;
+        while (lo < hi) {
+            const int32_t mid = lo + ((hi - lo) >> 1);
+            if ((int64_t)srcp[mid] < ra) lo = mid + 1; else hi = mid;
+        }
+        lb = lo;
+    }
+    const bool haslink = lb < l1 && (int64_t)srcp[lb] < ra + CS_R;
+    auto run_pf = [&](int eb) {
+        PF f{0, 0};
+        int32_t l = lb;
+#pragma unroll
+        for (int u = 0; u < CS_R; ++u) {
+            if (haslink)
+                while (l < l1 && (int64_t)srcp[l] == ra + u) { f = pf_compose(f, pf_of(termp[l], eb)); ++l; }   // Model.cs:85-88
+            f = pf_compose(f, pf_of(a_s[cs_pad(tid * CS_R + u)], eb));                                         // Model.cs:91-93,96-97
+        }
+        return f;
+    };
+    // ordered tree over the 256 runs; `keep` masks a run to the identity
+    auto reduce = [&](PF f) {
+        r0[tid] = f.d0;
+        r1[tid] = f.d1;
+        __syncthreads();
+        for (int st = 1; st < 256; st <<= 1) {
+            if ((tid & (2 * st - 1)) == 0) {
+                const PF r = pf_compose(PF{r0[tid], r1[tid]}, PF{r0[tid + st], r1[tid + st]});
+                r0[tid] = r.d0;
+                r1[tid] = r.d1;
+            }
+            __syncthreads();
+        }
+        const PF r{r0[0], r1[0]};
+        __syncthreads();
+        return r;
+    };
+    const PF f = run_pf(epre);
+    if (epost == epre) {
+        const PF tot = reduce(f);
+        if (tid == 0) { ek[oidx] = epre | (CS_PLAIN << CS_KIND_SHIFT); od0[oidx] = tot.d0; od1[oidx] = tot.d1; }
+        return;
+    }
+    // split: exclusive / inclusive prefix of the runs (wave scan + the four wave totals), located against the approximate
+    // incoming mantissa
+    PF inc = f;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        PF o;
+        o.d0 = __shfl_up(inc.d0, off, WAVE);
+        o.d1 = __shfl_up(inc.d1, off, WAVE);
+        if (lane >= off) inc = pf_compose(o, inc);
+    }
+    if (lane == WAVE - 1) { w0[wave] = inc.d0; w1[wave] = inc.d1; }
+    if (tid == 0) rstar = -1;
+    __syncthreads();
+    PF prew{0, 0};
+    for (int w = 0; w < wave; ++w) prew = pf_compose(prew, PF{w0[w], w1[w]});
+    PF exc;
+    exc.d0 = __shfl_up(inc.d0, 1, WAVE);
+    exc.d1 = __shfl_up(inc.d1, 1, WAVE);
+    if (lane == 0) exc = PF{0, 0};
+    exc = pf_compose(prew, exc);
+    inc = pf_compose(prew, inc);
+    const long long mt = (long long)(((unsigned long long)__double_as_longlong(pre) & CS_FRAC) | CS_HID);
+    if (mt + exc.d0 < CS_BIG && mt + inc.d0 >= CS_BIG) rstar = tid;      // (monotone: at most one run)
+    __syncthreads();
+    const int rs = rstar;
+    if (rs < 0) {
+        // the approximate sums say the binade is left, the scan does not: hand over the whole block under e; the carry checks
+        const PF tot = reduce(f);
+        if (tid == 0) { ek[oidx] = epre | (CS_PLAIN << CS_KIND_SHIFT); od0[oidx] = tot.d0; od1[oidx] = tot.d1; }
+        return;
+    }
+    if (tid == rs) { w0[0] = exc.d0; w1[0] = exc.d1; w0[1] = haslink ? 1 : 0; }
+    __syncthreads();
+    const PF before{w0[0], w1[0]};
+    const bool link_in_run = w0[1] != 0;
+    __syncthreads();
+    if (link_in_run) {
+        if (tid == 0) { ek[oidx] = epre | (CS_REDO << CS_KIND_SHIFT); od0[oidx] = 0; od1[oidx] = 0; }
+        return;
+    }
+    PF g{0, 0};
+    if (tid > rs) g = run_pf(epre + 1);
+    const PF after = reduce(g);
+    if (tid == 0) {
+        ek[oidx] = epre | (CS_SPLIT << CS_KIND_SHIFT);
+        od0[oidx] = before.d0;
+        od1[oidx] = before.d1;
+#pragma unroll
+        for (int u = 0; u < CS_R; ++u) sd[u] = a_s[cs_pad(rs * CS_R + u)];
+        sd[4] = __longlong_as_double(after.d0);
+        sd[5] = __longlong_as_double(after.d1);
+    }
+}
+
+// The single-seed carry: k_cs_carry<1>'s window walk, with the split and exact blocks applied from the window's registers;
+// only a failed check (or a CS_REDO block) costs a redone block.
+__global__ __launch_bounds__(64) void k_cs_carry1(int32_t n, int nchunks, const uint8_t *__restrict__ dangling,
+                                                  const double *__restrict__ X, double *__restrict__ Y,
+                                                  const int32_t *__restrict__ seeds, double c1,
+                                                  const int64_t *__restrict__ in_ptr, const int32_t *__restrict__ in_src,
+                                                  const int64_t *__restrict__ evoff, const double *__restrict__ evterm,
+                                                  const int32_t *__restrict__ lnk, const double *__restrict__ approx,
+                                                  const int32_t *__restrict__ ek, const long long *__restrict__ d0,
+                                                  const long long *__restrict__ d1, const double *__restrict__ side,
+                                                  uint32_t *__restrict__ nz_out, unsigned long long *__restrict__ redo_count)
+{
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    const int32_t sd = seeds[slot];
+    if (sd < 0) return;                                   // padding slot (whole wave)
+    const size_t base = (size_t)slot * nchunks;
+    double s = 0.0;
+    unsigned redo = 0;
+    struct Win {
+        double ap;
+        int32_t ek;
+        long long f0, f1;
+        v2d_t s01, s23, s45;                              // side words 0..5
+        double s6;
+    };
+    auto load = [&](int C, Win &w) {
+        const int cc = C + lane;
+        const bool v = cc < nchunks;
+        const size_t i = base + (v ? cc : nchunks - 1);
+        w.ap = v ? approx[i] : 0.0;
+        w.ek = ek[i];
+        w.f0 = d0[i];
+        w.f1 = d1[i];
+        const v2d_t *sp = reinterpret_cast<const v2d_t *>(side + i * CS_SIDE_WORDS);
+        w.s01 = sp[0];
+        w.s23 = sp[1];
+        w.s45 = sp[2];
+        w.s6 = side[i * CS_SIDE_WORDS + 6];
+    };
+    Win cur, nxt;
+    int c = 0;
+    int done = 0;                                         // blocks [c, c + done) of the window are already carried
+    load(0, cur);
+    nxt = cur;
+    while (c < nchunks) {
+        if (done == 0 && c + WAVE < nchunks) load(c + WAVE, nxt);
+        unsigned long long b = (unsigned long long)__double_as_longlong(s);
+        int eb = (int)((b >> 52) & 0x7ff);
+        bool normal = eb != 0 && eb != 0x7ff;
+        const int kind = cur.ek >> CS_KIND_SHIFT, ep = cur.ek & ((1 << CS_KIND_SHIFT) - 1);
+        const bool nz = cur.ap != 0.0 && lane >= done;    // (block sum 0 <=> every addend +0.0: the block is a no-op)
+        PF f{0, 0};
+        if (nz && kind == CS_PLAIN) { f.d0 = cur.f0; f.d1 = cur.f1; }
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            PF o;
+            o.d0 = __shfl_up(f.d0, off, WAVE);
+            o.d1 = __shfl_up(f.d1, off, WAVE);
+            if (lane >= off) f = pf_compose(o, f);
+        }
+        long long m = (long long)((b & CS_FRAC) | CS_HID);
+        const long long M = m + ((m & 1) ? f.d1 : f.d0);
+        const unsigned long long bad = __ballot(nz && (kind != CS_PLAIN || !normal || ep != eb || M >= CS_BIG));
+        if (!bad) {
+            if (normal) s = cs_from_m(eb, __shfl(M, WAVE - 1, WAVE));
+            c += WAVE;
+            done = 0;
+            cur = nxt;
+            continue;
+        }
+        const int L = __builtin_ctzll(bad);
+        if (L > 0 && normal) s = cs_from_m(eb, __shfl(M, L - 1, WAVE));   // the blocks before it (carried ones are identities)
+        // block c + L: its cells, wave-uniform
+        const int kL = __shfl(kind, L, WAVE), eL = __shfl(ep, L, WAVE);
+        b = (unsigned long long)__double_as_longlong(s);
+        eb = (int)((b >> 52) & 0x7ff);
+        normal = eb != 0 && eb != 0x7ff;
+        bool handled = false;
+        if (kL == CS_EXACT && b == 0ull) {
+            s = __shfl(cur.s6, L, WAVE);
+            handled = true;
+        } else if (kL == CS_SPLIT && normal && eL == eb && eb + 1 < 0x7ff) {
+            const PF before{__shfl(cur.f0, L, WAVE), __shfl(cur.f1, L, WAVE)};
+            m = (long long)((b & CS_FRAC) | CS_HID);
+            const long long M1 = m + ((m & 1) ? before.d1 : before.d0);
+            if (M1 < CS_BIG) {                            // still inside the binade in front of the run
+                double t = cs_from_m(eb, M1);
+                t += __shfl(cur.s01.x, L, WAVE);          // the run's four rows, real adds (Model.cs:91-93,96-97)
+                t += __shfl(cur.s01.y, L, WAVE);
+                t += __shfl(cur.s23.x, L, WAVE);
+                t += __shfl(cur.s23.y, L, WAVE);
+                const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+                if ((int)((tb >> 52) & 0x7ff) == eb + 1) {
+                    const PF after{__double_as_longlong(__shfl(cur.s45.x, L, WAVE)), __double_as_longlong(__shfl(cur.s45.y, L, WAVE))};
+                    const long long m2 = (long long)((tb & CS_FRAC) | CS_HID);
+                    const long long M2 = m2 + ((m2 & 1) ? after.d1 : after.d0);
+                    if (M2 < CS_BIG) {
+                        s = cs_from_m(eb + 1, M2);
+                        handled = true;
+                    }
+                }
+            }
+        }
+        if (!handled) {
+            s = cs_redo_block<1>(s, n, nchunks, c + L, slot, 0, dangling, X, seeds, c1, in_ptr, in_src, evoff, evterm, lnk);
+            ++redo;
+        }
+        done = L + 1;
+        if (done >= WAVE || c + done >= nchunks) {        // the window is exhausted
+            c += WAVE;
+            done = 0;
+            cur = nxt;
+        }
+    }
+    if (lane == 0) {
+        Y[(size_t)slot * (size_t)n + (size_t)sd] = s;
+        if (nz_out && s != 0.0) atomicOr(&nz_out[(size_t)slot * (((size_t)n + 31) / 32) + ((uint32_t)sd >> 5)], 1u << (sd & 31));
+        if (redo_count && redo) atomicAdd(redo_count, (unsigned long long)redo);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 
 static inline int cs_block_elems(int G) { return G == 1 ? CsGeom<1>::E : (G >= 16 ? CsGeom<16>::E : CsGeom<2>::E); }
@@ -444,6 +781,7 @@ int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, 
     RWR_TRY(g->cs_e.ensure(cells));
     RWR_TRY(g->cs_d0.ensure(cells));
     RWR_TRY(g->cs_d1.ensure(cells));
+    if (G == 1) RWR_TRY(g->cs_side.ensure(cells * CS_SIDE_WORDS));
     RWR_TRY(g->cs_lnk.ensure((size_t)tg * G * (size_t)(nchunks + 1)));
     if (!g->cs_redo.p) {
         RWR_TRY(g->cs_redo.alloc(1));
@@ -477,6 +815,7 @@ int32_t chain_scan_sum(rwr_graph *g, const double *D, double *out, hipStream_t s
     RWR_TRY(g->cs_e.ensure(cells));
     RWR_TRY(g->cs_d0.ensure(cells));
     RWR_TRY(g->cs_d1.ensure(cells));
+    RWR_TRY(g->cs_side.ensure(cells * CS_SIDE_WORDS));
     RWR_TRY(g->cs_lnk0.ensure((size_t)nchunks + 2));
     if (!g->cs_redo.p) {
         RWR_TRY(g->cs_redo.alloc(1));
@@ -504,6 +843,17 @@ static int32_t chain_scan_launch(rwr_graph *g, int G, int tg, const double *X, d
     CS_DISPATCH_G(G, hipLaunchKernelGGL((k_cs_block<GG, false>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X,
                                         d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, lnk,
                                         (const int32_t *)nullptr, g->cs_approx.p, (long long *)nullptr, (long long *)nullptr));
+    static const int split_env = [] { const char *e = RWR_TUNE_ENV("RWR_SCAN_SPLIT"); return e ? atoi(e) : 1; }();
+    if (G == 1 && split_env) {
+        // single seed: prediction, split and exact-start blocks in one pass; the carry applies them from registers
+        hipLaunchKernelGGL(k_cs_block1, grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X, d_seeds, c1, g->in_ptr.p, g->in_src.p,
+                           d_evoff, g->d_evterm.p, lnk, g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, g->cs_side.p);
+        hipLaunchKernelGGL(k_cs_carry1, dim3((unsigned)tg), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y, d_seeds, c1, g->in_ptr.p,
+                           g->in_src.p, d_evoff, g->d_evterm.p, lnk, g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, g->cs_side.p,
+                           nz_out, g->cs_redo.p);
+        RWR_HIP(hipGetLastError());
+        return RWR_OK;
+    }
     hipLaunchKernelGGL(k_cs_plan, dim3((unsigned)(tg * G)), dim3(64), 0, s, nchunks, d_seeds, g->cs_approx.p, g->cs_e.p);
     CS_DISPATCH_G(G, hipLaunchKernelGGL((k_cs_block<GG, true>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X,
                                         d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, lnk,

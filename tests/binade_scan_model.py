@@ -107,3 +107,51 @@ def chain_sum(addends, block=64):
         s = s + addends[q]                # the crossing add, in real fp64
         i = q + 1
     return s, fallbacks
+
+
+def split_block(pre_approx: float, block, run=4):
+    """What the single-seed block pass hands the carry for a block predicted to cross ONE binade boundary
+    (chain_scan.hip: k_cs_block1, CS_SPLIT): the run of `run` rows in which the APPROXIMATE incoming sum crosses, the
+    composed function of the runs before it (under e), the run's addends, and the composed function of the runs
+    behind it (under e + 1).  None when the scan finds no crossing run."""
+    eb = (bits(pre_approx) >> 52) & 0x7FF
+    assert 0 < eb < 0x7FE
+    mt = (bits(pre_approx) & ((1 << 52) - 1)) | (1 << 52)
+    runs = [block[i:i + run] for i in range(0, len(block), run)]
+    exc = (0, 0)
+    for r, rows in enumerate(runs):
+        f = (0, 0)
+        for a in rows:
+            f = compose(f, addend_func(a, eb))
+        inc = compose(exc, f)
+        if mt + exc[0] < BIG <= mt + inc[0]:
+            after = (0, 0)
+            for rows2 in runs[r + 1:]:
+                for a in rows2:
+                    after = compose(after, addend_func(a, eb + 1))
+            return {"eb": eb, "before": exc, "rows": list(rows), "after": after}
+        exc = inc
+    return None
+
+
+def apply_split(s: float, sp):
+    """The carry's side: function, real adds, function -- each part checked; None = a check failed (redo the block)."""
+    b = bits(s)
+    eb = (b >> 52) & 0x7FF
+    if sp is None or eb != sp["eb"]:
+        return None
+    m = (b & ((1 << 52) - 1)) | (1 << 52)
+    M1 = m + sp["before"][m & 1]
+    if M1 >= BIG:
+        return None
+    t = from_bits((eb << 52) | (M1 - (1 << 52)))
+    for a in sp["rows"]:
+        t = t + a
+    tb = bits(t)
+    if ((tb >> 52) & 0x7FF) != eb + 1:
+        return None
+    m2 = (tb & ((1 << 52) - 1)) | (1 << 52)
+    M2 = m2 + sp["after"][m2 & 1]
+    if M2 >= BIG:
+        return None
+    return from_bits(((eb + 1) << 52) | (M2 - (1 << 52)))

@@ -3,6 +3,7 @@
 import random
 import struct
 
+from tests import binade_scan_model as m
 from tests.binade_scan_model import addend_func, chain_sum, bits, from_bits
 
 
@@ -65,3 +66,42 @@ def test_addend_func_edges():
     assert addend_func(u * 1.5, eb) == (2, 1)
     assert addend_func(u * 0.75, eb) == (1, 1)
     assert addend_func(5e-324, eb) == (0, 0)
+
+
+def test_split_blocks_are_exact_or_refused():
+    """chain_scan.hip's CS_SPLIT blocks: located with an APPROXIMATE incoming sum, applied to the EXACT one.  Whenever the
+    carry's checks pass the result is the sequential sum bit for bit; a perturbed prediction may only make them fail."""
+    rng = random.Random(20260105)
+    accepted = refused = 0
+    for trial in range(400):
+        n_front = rng.randrange(50, 400)
+        front = [rng.random() * 1e-3 for _ in range(n_front)]
+        s = seq_sum(front)
+        # a block that takes the sum across exactly one binade boundary
+        eb = (m.bits(s) >> 52) & 0x7FF
+        top = m.from_bits((eb + 1) << 52)
+        need = top - s
+        rows = rng.choice([64, 256, 1024])
+        block = [need * 1.3 / rows * (0.5 + rng.random()) for _ in range(rows)]
+        if trial % 7 == 0:                                   # half-way cases: addends that are multiples of half an ulp
+            u = m.from_bits((eb - 52) << 52) if eb > 52 else 0.0
+            block = [round(a / (u / 2)) * (u / 2) if u else a for a in block]
+        want = s
+        for a in block:
+            want = want + a
+        if ((m.bits(want) >> 52) & 0x7FF) != eb + 1:
+            continue
+        # the prediction: exact, or off by a few thousand ulps either way, or grossly off
+        err = rng.choice([0.0, 1e-13, -1e-13, 3e-12, -3e-12, 1e-6, -1e-6])
+        pre = s * (1.0 + err)
+        if ((m.bits(pre) >> 52) & 0x7FF) != eb:
+            continue
+        sp = m.split_block(pre, block)
+        got = m.apply_split(s, sp)
+        if got is None:
+            refused += 1
+            assert abs(err) > 0 or sp is None
+        else:
+            accepted += 1
+            assert m.bits(got) == m.bits(want), (trial, err)
+    assert accepted > 150 and refused > 0
