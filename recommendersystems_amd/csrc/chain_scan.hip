@@ -49,6 +49,13 @@ template <int G> struct CsGeom {
     static constexpr int CH = E / G;                    // rows per block
 };
 __device__ __forceinline__ int cs_pad(int q) { return q + (q >> 4); }
+// The addend of link l of the seed's in-list (Model.cs:84,87 for target == seed): precomputed by k_seed_terms (termp), or --
+// value-free graphs, evoff == nullptr -- gathered here from the z matrix, whose entries ARE those addends (zt = the seed's
+// column of its tile).
+__device__ __forceinline__ double cs_term(const double *termp, const double *zt, const int32_t *srcp, int32_t l, int G)
+{
+    return zt ? zt[(size_t)srcp[l] * G] : termp[l];
+}
 
 // lnk[slot][c] = number of the seed's in-links whose source row is < c * CH  (c = 0..nchunks)
 __global__ __launch_bounds__(256) void k_cs_links(int nchunks, int CH, const int64_t *__restrict__ in_ptr,
@@ -102,12 +109,15 @@ __global__ __launch_bounds__(256) void k_cs_block(int32_t n, int nchunks, const 
     // this block's share of the seed's in-link list (sorted by source row)
     int32_t l1 = 0, a0 = 0;
     const int32_t *srcp = in_src;
-    const double *termp = evterm;
+    const double *termp = evterm, *zt = nullptr;
     if (s >= 0) {
         const int32_t *lk = lnk + (size_t)slot * (size_t)(nchunks + 1) + c;
         a0 = lk[0];
         l1 = lk[1];
-        if (l1 > a0) { srcp = in_src + in_ptr[s]; termp = evterm + evoff[slot]; }
+        if (l1 > a0) {
+            srcp = in_src + in_ptr[s];
+            if (evoff) termp = evterm + evoff[slot]; else zt = evterm + (size_t)tile * (size_t)n * G + k;
+        }
     }
     const size_t oidx = (size_t)slot * nchunks + c;
     const int eb = FUNCS ? e_pred[oidx] : 0;
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(256) void k_cs_block(int32_t n, int nchunks, const 
 #pragma unroll
             for (int u = 0; u < CS_R; ++u) {
                 const int64_t row = ra + u;
-                while (l < l1 && (int64_t)srcp[l] == row) { f = pf_compose(f, pf_of(termp[l], eb)); ++l; }   // Model.cs:85-88
+                while (l < l1 && (int64_t)srcp[l] == row) { f = pf_compose(f, pf_of(cs_term(termp, zt, srcp, l, G), eb)); ++l; }   // Model.cs:85-88
                 f = pf_compose(f, pf_of(a_s[cs_pad((rl * CS_R + u) * G + k)], eb));                        // Model.cs:91-93,96-97
             }
             r0[tid] = f.d0;
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256) void k_cs_block(int32_t n, int nchunks, const 
 #pragma unroll
             for (int u = 0; u < CS_R; ++u) {
                 const int64_t row = ra + u;
-                while (l < l1 && (int64_t)srcp[l] == row) { acc += termp[l]; ++l; }
+                while (l < l1 && (int64_t)srcp[l] == row) { acc += cs_term(termp, zt, srcp, l, G); ++l; }
                 acc += a_s[cs_pad((rl * CS_R + u) * G + k)];
             }
             double *racc = reinterpret_cast<double *>(r0);
@@ -236,7 +246,8 @@ __device__ double cs_redo_block(double s, int32_t n, int nchunks, int c, int til
     const int32_t *lk = lnk + (size_t)slot * (size_t)(nchunks + 1) + c;
     const int32_t a0 = lk[0], a1 = lk[1];
     const int32_t *srcp = in_src + in_ptr[sd];
-    const double *termp = evterm + evoff[slot];
+    const double *termp = evoff ? evterm + evoff[slot] : nullptr;
+    const double *zt = evoff ? nullptr : evterm + (size_t)tile * (size_t)n * G + kk;
     const double *xk = X + (size_t)tile * (size_t)n * G + kk;
     // the block's restart addends, fetched in one burst (16 loads in flight per lane) and parked in LDS (run-major reads
     // are conflict-free with one pad slot per 64)
@@ -288,7 +299,7 @@ __device__ double cs_redo_block(double s, int32_t n, int nchunks, int c, int til
 #pragma unroll
                 for (int u = 0; u < R; ++u) {
                     if (haslink)
-                        while (q < a1 && (int64_t)srcp[q] == row0 + u) { f = pf_compose(f, pf_of(termp[q], eb)); ++q; }
+                        while (q < a1 && (int64_t)srcp[q] == row0 + u) { f = pf_compose(f, pf_of(cs_term(termp, zt, srcp, q, G), eb)); ++q; }
                     f = pf_compose(f, pf_of(red_a[lane * R + u + ((lane * R + u) >> 6)], eb));
                 }
             }
@@ -315,7 +326,7 @@ __device__ double cs_redo_block(double s, int32_t n, int nchunks, int c, int til
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 if (haslink)
-                    while (q < a1 && (int64_t)srcp[q] == row0 + u) { t += termp[q]; ++q; }   // Model.cs:85-88
+                    while (q < a1 && (int64_t)srcp[q] == row0 + u) { t += cs_term(termp, zt, srcp, q, G); ++q; }   // Model.cs:85-88
                 t += red_a[lane * R + u + ((lane * R + u) >> 6)];                              // Model.cs:91-93,96-97
             }
         }
@@ -334,7 +345,8 @@ __global__ __launch_bounds__(64) void k_cs_carry(int32_t n, int nchunks, const u
                                                  const int32_t *__restrict__ lnk, const double *__restrict__ approx,
                                                  const int32_t *__restrict__ e_pred, const long long *__restrict__ d0,
                                                  const long long *__restrict__ d1, uint32_t *__restrict__ nz_out,
-                                                 unsigned long long *__restrict__ redo_count, int direct)
+                                                 unsigned long long *__restrict__ redo_count, int direct,
+                                                 double *__restrict__ zout = nullptr, const double *__restrict__ w_src = nullptr)
 {
     const int slot = blockIdx.x, lane = threadIdx.x;
     const int tile = slot / G, k = slot % G;
@@ -350,6 +362,7 @@ __global__ __launch_bounds__(64) void k_cs_carry(int32_t n, int nchunks, const u
             s = cs_redo_block<G>(s, n, nchunks, c, tile, k, dangling, X, seeds, c1, in_ptr, in_src, evoff, evterm, lnk);
         if (lane == 0) {
             Y[(size_t)tile * (size_t)n * G + (size_t)sd * G + k] = s;
+            if (zout) { const double rw = c1 * s; zout[(size_t)tile * (size_t)n * G + (size_t)sd * G + k] = rw * w_src[sd]; }   // Model.cs:84,87
             if (nz_out && s != 0.0)
                 atomicOr(&nz_out[(size_t)tile * (((size_t)n + 31) / 32) + ((uint32_t)sd >> 5)], 1u << (sd & 31));
         }
@@ -495,12 +508,15 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
     // this block's share of the seed's in-link list (sorted by source row)
     int32_t l1 = 0, a0 = 0;
     const int32_t *srcp = in_src;
-    const double *termp = evterm;
+    const double *termp = evterm, *zt = nullptr;
     if (s >= 0) {
         const int32_t *lk = lnk + (size_t)slot * (size_t)(nchunks + 1) + c;
         a0 = lk[0];
         l1 = lk[1];
-        if (l1 > a0) { srcp = in_src + in_ptr[s]; termp = evterm + evoff[slot]; }
+        if (l1 > a0) {
+            srcp = in_src + in_ptr[s];
+            if (evoff) termp = evterm + evoff[slot]; else zt = evterm + (size_t)slot * (size_t)n;
+        }
     }
     if (pre == 0.0) {
         // nothing non-zero in front: the sum enters as exactly +0.0 and one thread adds the block up in the reference's order
@@ -514,7 +530,7 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
                 if (l < l1 && (int64_t)srcp[l] < row0 + u0 + 16) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
-                        while (l < l1 && (int64_t)srcp[l] == row0 + u0 + k) { t += termp[l]; ++l; }   // Model.cs:85-88
+                        while (l < l1 && (int64_t)srcp[l] == row0 + u0 + k) { t += cs_term(termp, zt, srcp, l, 1); ++l; }   // Model.cs:85-88
                         t += v[k];                                                                     // Model.cs:91-93,96-97
                     }
                 } else {
@@ -553,7 +569,7 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
 #pragma unroll
         for (int u = 0; u < CS_R; ++u) {
             if (haslink)
-                while (l < l1 && (int64_t)srcp[l] == ra + u) { f = pf_compose(f, pf_of(termp[l], eb)); ++l; }   // Model.cs:85-88
+                while (l < l1 && (int64_t)srcp[l] == ra + u) { f = pf_compose(f, pf_of(cs_term(termp, zt, srcp, l, 1), eb)); ++l; }   // Model.cs:85-88
             f = pf_compose(f, pf_of(a_s[cs_pad(tid * CS_R + u)], eb));                                         // Model.cs:91-93,96-97
         }
         return f;
@@ -645,7 +661,8 @@ __global__ __launch_bounds__(64) void k_cs_carry1(int32_t n, int nchunks, const 
                                                   const int32_t *__restrict__ lnk, const double *__restrict__ approx,
                                                   const int32_t *__restrict__ ek, const long long *__restrict__ d0,
                                                   const long long *__restrict__ d1, const double *__restrict__ side,
-                                                  uint32_t *__restrict__ nz_out, unsigned long long *__restrict__ redo_count)
+                                                  uint32_t *__restrict__ nz_out, unsigned long long *__restrict__ redo_count,
+                                                  double *__restrict__ zout, const double *__restrict__ w_src)
 {
     const int slot = blockIdx.x, lane = threadIdx.x;
     const int32_t sd = seeds[slot];
@@ -751,6 +768,8 @@ __global__ __launch_bounds__(64) void k_cs_carry1(int32_t n, int nchunks, const 
     }
     if (lane == 0) {
         Y[(size_t)slot * (size_t)n + (size_t)sd] = s;
+        // value-free path: the seed row's own z for the next step (the SpMV leaves the seed's row alone)
+        if (zout) { const double rw = c1 * s; zout[(size_t)slot * (size_t)n + (size_t)sd] = rw * w_src[sd]; }   // Model.cs:84,87
         if (nz_out && s != 0.0) atomicOr(&nz_out[(size_t)slot * (((size_t)n + 31) / 32) + ((uint32_t)sd >> 5)], 1u << (sd & 31));
         if (redo_count && redo) atomicAdd(redo_count, (unsigned long long)redo);
     }
@@ -795,12 +814,22 @@ int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, 
 
 // one step's seed-row chain for a tile group (the link terms d_evterm must already be on the stream)
 static int32_t chain_scan_launch(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,
-                                 const int64_t *d_evoff, double c1, uint32_t *nz_out, const int32_t *lnk, hipStream_t s);
+                                 const int64_t *d_evoff, double c1, uint32_t *nz_out, const int32_t *lnk, hipStream_t s,
+                                 const double *zterms = nullptr, double *zout = nullptr);
+
+static bool cs_split_enabled()
+{
+    static const int split_env = [] { const char *e = RWR_TUNE_ENV("RWR_SCAN_SPLIT"); return e ? atoi(e) : 1; }();
+    return split_env != 0;
+}
+// single seed per tile: the chain gathers the link terms itself on value-free graphs (no k_seed_terms launch) and writes the
+// seed row's z for the next step (no k_seed_z launch)
+bool chain_scan_self_contained(int G) { return G == 1 && cs_split_enabled(); }
 
 int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,
-                        const int64_t *d_evoff, double c1, uint32_t *nz_out, hipStream_t s)
+                        const int64_t *d_evoff, double c1, uint32_t *nz_out, hipStream_t s, const double *zterms, double *zout)
 {
-    return chain_scan_launch(g, G, tg, X, Y, d_seeds, d_evoff, c1, nz_out, g->cs_lnk.p, s);
+    return chain_scan_launch(g, G, tg, X, Y, d_seeds, d_evoff, c1, nz_out, g->cs_lnk.p, s, zterms, zout);
 }
 
 // The reference's checkConvergence (Model.cs:110-115) is the same kind of chain: diff += |rank[i] - nextRank[i]| over
@@ -828,32 +857,41 @@ int32_t chain_scan_sum(rwr_graph *g, const double *D, double *out, hipStream_t s
 }
 
 static int32_t chain_scan_launch(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,
-                                 const int64_t *d_evoff, double c1, uint32_t *nz_out, const int32_t *lnk, hipStream_t s)
+                                 const int64_t *d_evoff, double c1, uint32_t *nz_out, const int32_t *lnk, hipStream_t s,
+                                 const double *zterms, double *zout)
 {
     const int nchunks = cs_nchunks(g->n, G);
     const dim3 grid((unsigned)nchunks, (unsigned)tg);
     static const int direct_max = [] { const char *e = RWR_TUNE_ENV("RWR_SCAN_DIRECT_BLOCKS"); return e ? atoi(e) : 8; }();
+    // single seed per tile: link terms gathered from the z matrix when the caller hands it over (evoff = nullptr tells the
+    // kernels), the seed row's next z written by the carry
+    const bool self = chain_scan_self_contained(G);
+    const int64_t *evo = (self && zterms) ? nullptr : d_evoff;
+    const double *evt = (self && zterms) ? zterms : g->d_evterm.p;
     if (nchunks <= direct_max) {
         CS_DISPATCH_G(G, hipLaunchKernelGGL(k_cs_carry<GG>, dim3((unsigned)(tg * G)), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y,
-                                            d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, lnk,
-                                            g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, nz_out, g->cs_redo.p, 1));
+                                            d_seeds, c1, g->in_ptr.p, g->in_src.p, evo, evt, lnk,
+                                            g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, nz_out, g->cs_redo.p, 1,
+                                            self ? zout : (double *)nullptr, g->w_src.p));
+        RWR_HIP(hipGetLastError());
+        return RWR_OK;
+    }
+    if (self) {
+        // prediction, split and exact-start blocks in one pass; the carry applies them from registers
+        hipLaunchKernelGGL((k_cs_block<1, false>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X, d_seeds, c1, g->in_ptr.p,
+                           g->in_src.p, evo, evt, lnk, (const int32_t *)nullptr, g->cs_approx.p, (long long *)nullptr,
+                           (long long *)nullptr);
+        hipLaunchKernelGGL(k_cs_block1, grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X, d_seeds, c1, g->in_ptr.p, g->in_src.p,
+                           evo, evt, lnk, g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, g->cs_side.p);
+        hipLaunchKernelGGL(k_cs_carry1, dim3((unsigned)tg), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y, d_seeds, c1, g->in_ptr.p,
+                           g->in_src.p, evo, evt, lnk, g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, g->cs_side.p, nz_out,
+                           g->cs_redo.p, zout, g->w_src.p);
         RWR_HIP(hipGetLastError());
         return RWR_OK;
     }
     CS_DISPATCH_G(G, hipLaunchKernelGGL((k_cs_block<GG, false>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X,
                                         d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, lnk,
                                         (const int32_t *)nullptr, g->cs_approx.p, (long long *)nullptr, (long long *)nullptr));
-    static const int split_env = [] { const char *e = RWR_TUNE_ENV("RWR_SCAN_SPLIT"); return e ? atoi(e) : 1; }();
-    if (G == 1 && split_env) {
-        // single seed: prediction, split and exact-start blocks in one pass; the carry applies them from registers
-        hipLaunchKernelGGL(k_cs_block1, grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X, d_seeds, c1, g->in_ptr.p, g->in_src.p,
-                           d_evoff, g->d_evterm.p, lnk, g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, g->cs_side.p);
-        hipLaunchKernelGGL(k_cs_carry1, dim3((unsigned)tg), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y, d_seeds, c1, g->in_ptr.p,
-                           g->in_src.p, d_evoff, g->d_evterm.p, lnk, g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, g->cs_side.p,
-                           nz_out, g->cs_redo.p);
-        RWR_HIP(hipGetLastError());
-        return RWR_OK;
-    }
     hipLaunchKernelGGL(k_cs_plan, dim3((unsigned)(tg * G)), dim3(64), 0, s, nchunks, d_seeds, g->cs_approx.p, g->cs_e.p);
     CS_DISPATCH_G(G, hipLaunchKernelGGL((k_cs_block<GG, true>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X,
                                         d_seeds, c1, g->in_ptr.p, g->in_src.p, d_evoff, g->d_evterm.p, lnk,

@@ -177,7 +177,9 @@ int32_t recommend_small(rwr_graph *g, int32_t seed, double d, int32_t n_iter, in
 // chain_scan.hip: the exact seed-row chain as a parallel binade scan
 int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, hipStream_t s);
 int32_t chain_scan_step(rwr_graph *g, int G, int tg, const double *X, double *Y, const int32_t *d_seeds,
-                        const int64_t *d_evoff, double c1, uint32_t *nz_out, hipStream_t s);
+                        const int64_t *d_evoff, double c1, uint32_t *nz_out, hipStream_t s, const double *zterms = nullptr,
+                        double *zout = nullptr);
+bool chain_scan_self_contained(int G);   // G == 1: no k_seed_terms / k_seed_z launches around the step
 int32_t chain_scan_collect(rwr_graph *g, hipStream_t s);
 int32_t chain_scan_sum(rwr_graph *g, const double *D, double *out, hipStream_t s);   // exact sequential sum of n addends >= 0
 

@@ -819,6 +819,10 @@ struct GroupIter {
         //  on the 6 M-node graph, +10 % on the 0.6 M-node one)
         if (G == 1 && tg == 1 && act_env < 0 && act_iters == 2 && g->n >= spmv_big_n()) act_iters = 3;
         if (G == 1 && tg == 1 && spmm_variant != 0 && g->nonneg) nz_iters = act_iters;
+        // (a single seed on a graph of ego-network size: marking the frontier takes longer than the dense step it replaces --
+        //  measured 38 us against 8 at 12 K nodes, 25 against 28 at 120 K)
+        static const int64_t act_min_n = [] { const char *e = RWR_TUNE_ENV("RWR_ACT_MIN_N"); return e ? atol(e) : 200000l; }();
+        if (G == 1 && tg == 1 && act_env < 0 && n < act_min_n) nz_iters = act_iters = 0;
         if (!fresh) nz_iters = act_iters = 0;
         const size_t nzw = ((size_t)n + 31) / 32;
         nz_cur = nz_iters > 0 ? g->d_nz.p : nullptr;
@@ -874,6 +878,7 @@ struct GroupIter {
         // (while X is sparse the bitmap-walking chain serves a whole tile at once; for a single seed the scan is cheaper)
         const bool scan_now = scan && (!act || G == 1);
         bool scan_side = false;
+        bool seed_z_done = false;
         if (scan_now) {
             // the parallel chain.  Batches: on the main stream, ahead of the SpMM (which skips the seed rows).  A single seed:
             // on the second stream BESIDE the SpMV -- the two read the same vectors and write disjoint rows, and for one seed
@@ -888,10 +893,14 @@ struct GroupIter {
                 RWR_HIP(hipEventRecord(g->ev_fork, s));
                 RWR_HIP(hipStreamWaitEvent(s2, g->ev_fork, 0));
             }
-            RWR_DISPATCH_G(G, launch_seed_terms<GG>(g, tg, X, d_seeds, c1, d_evoff, sc, Zc));
+            // (a single seed per tile: the chain kernels gather the link terms from z themselves and leave the seed row's next z)
+            const bool self = chain_scan_self_contained(G);
+            seed_z_done = self;
+            if (!(self && Zc)) RWR_DISPATCH_G(G, launch_seed_terms<GG>(g, tg, X, d_seeds, c1, d_evoff, sc, Zc));
             hipEvent_t c0 = nullptr, c1e = nullptr;
             if (prof) { c0 = pool.get(); c1e = pool.get(); RWR_HIP(hipEventRecord(c0, sc)); }
-            RWR_TRY(chain_scan_step(g, G, tg, X, Y, d_seeds, d_evoff, c1, nz_out, sc));
+            RWR_TRY(chain_scan_step(g, G, tg, X, Y, d_seeds, d_evoff, c1, nz_out, sc, self ? Zc : nullptr,
+                                    (self && Zc && !last) ? Zn : nullptr));
             if (prof) { RWR_HIP(hipEventRecord(c1e, sc)); chain_ev.push_back(c0); chain_ev.push_back(c1e); }
             if (scan_side) RWR_HIP(hipEventRecord(g->ev_join, s2));
             s2 = s;
@@ -920,7 +929,7 @@ struct GroupIter {
         if (!nz_in) { g->stats.spmm_dense_launches += 1; ++dense_steps; }
         if ((s2 != s && !scan_now) || scan_side) RWR_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
         // value-free path: the seed rows' own z, now that the seed-row kernel has left their rank in Y
-        if (zout) hipLaunchKernelGGL(k_seed_z, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, Y, zout, d_seeds, g->w_src.p, c1);
+        if (zout && !seed_z_done) hipLaunchKernelGGL(k_seed_z, dim3(cdiv((size_t)tg * G, 64)), dim3(64), 0, s, n, tg, G, Y, zout, d_seeds, g->w_src.p, c1);
         RWR_HIP(hipGetLastError());
         { double *t = X; X = Y; Y = t; }   // Model.updateRanks (Model.cs:103-108)
         { double *t = Zc; Zc = Zn; Zn = t; }

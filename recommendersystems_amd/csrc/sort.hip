@@ -185,7 +185,8 @@ int32_t radix_sort_pairs(KeyT *keys, KeyT *keys_alt, uint32_t *vals, uint32_t *v
         return RWR_E_INVALID;
     }
     static const int small_env = [] { const char *e = RWR_TUNE_ENV("RWR_SMALL_SORT"); return e ? atoi(e) : 1; }();
-    if (small_env && nseg == 1 && m <= SMALL_SORT_MAX) {
+    static const size_t small_max = [] { const char *e = RWR_TUNE_ENV("RWR_SMALL_SORT_MAX"); return e ? (size_t)atol(e) : SMALL_SORT_MAX; }();
+    if (small_env && nseg == 1 && m <= small_max) {
         hipLaunchKernelGGL(k_sort_small<KeyT>, dim3(1), dim3(SMALL_SORT_THREADS), 0, stream, keys, keys_alt, vals, vals_alt,
                            (uint32_t)m, key_bits);
         RWR_HIP(hipGetLastError());

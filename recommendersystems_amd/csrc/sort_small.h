@@ -7,7 +7,9 @@ namespace rwr {
 
 constexpr int SMALL_SORT_RADIX = 256;
 constexpr int SMALL_SORT_THREADS = 1024;
-constexpr size_t SMALL_SORT_MAX = 8192;
+// (one workgroup needs ~1.5 us per tile of 1024 keys and pass, the general path three launches ~ 50 us per pass whatever the
+//  size: break-even near 32 K keys)
+constexpr size_t SMALL_SORT_MAX = 20480;
 
 // LDS the sort needs (declared by the calling kernel so that several stages can share one workgroup)
 struct SmallSortLds {

@@ -256,12 +256,12 @@ __global__ __launch_bounds__(WAVE, 3) void k_spmv_exact_hub(int32_t r0, int32_t 
                                                          const int32_t *__restrict__ row_order,
                                                          const double *__restrict__ x, double *__restrict__ y,
                                                          const int32_t *__restrict__ seeds, double c1, int skip_seed_row,
-                                                         const double *__restrict__ w_src, double *__restrict__ zout, int prefix)
+                                                         const double *__restrict__ w_src, double *__restrict__ zout, int prefix,
+                                                         const uint32_t *__restrict__ act, uint32_t *__restrict__ nz_out)
 {
     __shared__ double pb[2][WAVE];
     const int lane = threadIdx.x;
     const int32_t my_seed = skip_seed_row ? seeds[0] : -1;
-    uint32_t *nz_out = nullptr;
     // a hub row is one long dependent chain: beside the sweep kernel (sweep.hip), whose waves are many and mostly waiting at
     // barriers, this wave should win the SIMD's issue arbitration
     __builtin_amdgcn_s_setprio(3);
@@ -269,7 +269,9 @@ __global__ __launch_bounds__(WAVE, 3) void k_spmv_exact_hub(int32_t r0, int32_t 
         const int32_t j = row_order[r];
         if (j == my_seed) continue;
         int64_t p = in_ptr[j];
-        const int64_t e = in_ptr[j + 1];
+        int64_t e = in_ptr[j + 1];
+        // first iterations: a row none of whose in-neighbours holds a non-zero (k_mark_active) stays exactly +0.0
+        if (act && !((act[(uint32_t)j >> 5] >> (j & 31)) & 1u)) e = p;
         double acc = 0.0;
         {   // the first `prefix` entries one by one (the shape of spmv_exact_wave)
             const int64_t ea = (e - p) < prefix ? e : p + prefix;
@@ -374,7 +376,9 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
     // hub rows (>= hub_t in-links, first in the in-degree order): exact parallel reduction, one wave per row, on a stream of
     // its own beside the binned kernel (dense steps only, and only when every addend is known to be >= 0)
     static const int hub_env = [] { const char *e = getenv("RWR_HUB_SCAN"); return e ? atoi(e) : 1; }();
-    const bool hubs = sweep || (hub_scan && hub_env && by_degree && !act && !nz_out && g->stream3 && s != g->stream3);
+    // (also in the frontier iterations: a hub row that IS active costs its whole list there too -- left to the binned kernel's
+    //  wave-per-row walk, the one active 24 K-link row of the MovieLens-shaped graph made the sparse first step 324 us long)
+    const bool hubs = sweep || (hub_scan && hub_env && by_degree && g->stream3 && s != g->stream3);
     bool forked = false;
     auto fork = [&]() {
         if (forked) return;
@@ -393,10 +397,10 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
         const size_t hub_lds = sweep ? (size_t)hub_lds_env : 0;
         if (vf)
             hipLaunchKernelGGL(k_spmv_exact_hub<true>, dim3(grid), dim3(WAVE), hub_lds, g->stream3, ra, ra + nh, g->in_ptr.p, g->in_src.p,
-                               g->in_w.p, order, gs, Y, seeds, c1, skip, g->w_src.p, zout, prefix);
+                               g->in_w.p, order, gs, Y, seeds, c1, skip, g->w_src.p, zout, prefix, act, nz_out);
         else
             hipLaunchKernelGGL(k_spmv_exact_hub<false>, dim3(grid), dim3(WAVE), hub_lds, g->stream3, ra, ra + nh, g->in_ptr.p, g->in_src.p,
-                               g->in_w.p, order, gs, Y, seeds, c1, skip, g->w_src.p, zout, prefix);
+                               g->in_w.p, order, gs, Y, seeds, c1, skip, g->w_src.p, zout, prefix, act, nz_out);
     };
     auto blocks_for = [](int64_t rows, int W) { const int64_t b = (rows * W + 255) / 256; return (int)(b < 0 ? 0 : (b > 16384 ? 16384 : b)); };
     auto launch = [&](const int32_t *order, int32_t ra0, int32_t rows, const int32_t bins[3], int32_t nh) {
