@@ -271,7 +271,8 @@ def bench_c1(args):
     """BASELINE.json configs[0] the way the reference's host runs it (Program.cs:11,61-66; Experiment.cs:46,69,104-128): for
     every ego network, 16 methodologies x 3 folds = 48 slightly different graphs, each built (Graph ctor + buildGraph),
     walked from seed 0 (Recommendation(0, 0.15f, T)) and evaluated (Hits / AP over the full list), from 10 concurrent host
-    threads with a handle each.  The graphs are produced beforehand by the restated loader (tests/tweet_harness.py, the
+    threads.  `value`: every thread hands its share of the graphs to one rwr_eval_graphs call; `one_call_per_graph`: the same
+    threads with a handle per graph (create + recommend_eval + destroy).  The graphs are produced beforehand by the restated loader (tests/tweet_harness.py, the
     reference's DataLoader / SQLiteAdapter flow over synthetic <ego>.sqlite files) and flattened; the timed region is
     rwr_graph_create + rwr_recommend_eval + rwr_graph_destroy per graph through the C-ABI.  One STEP = one pass over all
     graphs.  cpu_baseline = the same loop over the C restatement of the reference (oracle/), same thread count; every
@@ -312,11 +313,21 @@ def bench_c1(args):
            f"{min(links)}..{max(links)} links) loaded in {time.time() - t0:.1f}s")
     names = ("node_id", "node_type", "rowptr", "dst", "etype", "w")
 
+    from concurrent.futures import ThreadPoolExecutor
+    from recommendersystems_amd.rwr_based import EvaluateGraphs
+    flat_graphs = [Graph.from_flat(**dict(zip(names, f[0]))) for f in graphs]     # (host arrays only: nothing is built here)
+    pool = ThreadPoolExecutor(max_workers=args.host_threads)     # the harness's threads live for the whole run (Program.cs:11)
+
+    def run_on_threads(worker):
+        for f in [pool.submit(worker, t) for t in range(args.host_threads)]:
+            f.result()
+
     def gpu_pass(results):
+        # a handle per graph: create + recommend_eval + destroy, graphs dealt to the threads as they become free
         nxt = iter(range(len(graphs)))
         lock = threading.Lock()
 
-        def worker():
+        def worker(_t):
             while True:
                 with lock:
                     i = next(nxt, None)
@@ -327,21 +338,36 @@ def bench_c1(args):
                 G.buildGraph()
                 results[i] = Recommender(G).RecommendationEval(0, DAMPING, T_ITER, test)
                 G.close()
-        ts = [threading.Thread(target=worker) for _ in range(args.host_threads)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
+        run_on_threads(worker)
 
+    def gpu_pass_batched(results):
+        # the same threads, each handing its share of the graphs to ONE rwr_eval_graphs call (a workgroup per graph)
+        nt = args.host_threads
+        per = (len(graphs) + nt - 1) // nt
+
+        def worker(t):
+            lo, hi = t * per, min(len(graphs), (t + 1) * per)
+            if lo >= hi:
+                return
+            h, sp, ln = EvaluateGraphs(flat_graphs[lo:hi], [0] * (hi - lo), DAMPING, T_ITER, [graphs[i][1] for i in range(lo, hi)])
+            for i in range(lo, hi):
+                results[i] = (int(h[i - lo]), float(sp[i - lo]), int(ln[i - lo]))
+        run_on_threads(worker)
+
+    def timed(fn, results):
+        for _ in range(args.warmup):
+            fn(results)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn(results)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    res_single = [None] * len(graphs)
+    elapsed_single = timed(gpu_pass, res_single)
     res = [None] * len(graphs)
-    for _ in range(args.warmup):
-        gpu_pass(res)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gpu_pass(res)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(gpu_pass_batched, res)
     value = len(graphs) * args.steps / elapsed
     out = {"metric": "ego-network evaluations/s (Graph.buildGraph + Recommendation(0, 0.15f, T) + Hits/AP per graph)", "value": value,
            "unit": "graphs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -351,8 +377,13 @@ def bench_c1(args):
                                   f"full list evaluated, {args.host_threads} host threads (Program.cs:11)",
                       "graphs": len(graphs), "host_threads": args.host_threads, "iterations": T_ITER},
            "ms_per_graph": 1e3 * elapsed / (args.steps * len(graphs)),
-           "roofline": None, "roofline_note": "latency-bound by design: every graph is one k_small_rwr launch (one workgroup) "
-                                              "plus its build; see DESIGN.md 3.6"}
+           "entry_point": "rwr_eval_graphs: every host thread hands its share of the graphs to one call (one build launch, one "
+                          "iteration launch, one evaluation launch per call, a workgroup per graph)",
+           "one_call_per_graph": {"value": len(graphs) * args.steps / elapsed_single, "unit": "graphs/s",
+                                  "entry_points": "rwr_graph_create + rwr_recommend_eval + rwr_graph_destroy per graph, same threads",
+                                  "results_identical_to_batched": res_single == res},
+           "roofline": None, "roofline_note": "latency-bound by design: every graph is one workgroup of the build kernel and one "
+                                              "of the iteration kernel; see DESIGN.md 3.6"}
     if not args.no_cpu_baseline:
         from oracle.c_oracle import FlatGraph, evaluate
         cres = [None] * len(graphs)
@@ -361,7 +392,7 @@ def bench_c1(args):
             nxt = iter(range(len(graphs)))
             lock = threading.Lock()
 
-            def worker():
+            def worker(_t):
                 while True:
                     with lock:
                         i = next(nxt, None)
@@ -371,11 +402,7 @@ def bench_c1(args):
                     F = FlatGraph(*flat)
                     ids, _ = F.recommend(0, DAMPING, T_ITER)
                     cres[i] = evaluate(ids, test) + (len(ids),)
-            ts = [threading.Thread(target=worker) for _ in range(args.host_threads)]
-            for t in ts:
-                t.start()
-            for t in ts:
-                t.join()
+            run_on_threads(worker)
         t1 = time.perf_counter()
         cpu_pass()
         t_cpu = time.perf_counter() - t1

@@ -206,6 +206,30 @@ int32_t rwr_recommend_eval_batch(rwr_graph *g, const int32_t *seeds, int32_t K, 
                                  const int64_t *test_ptr, const int64_t *test_ids, int64_t *n_hits,
                                  double *sum_precision, int64_t *list_len);
 
+/* ---- Many small graphs at once ---------------------------------------------------------
+ * The reference's own workload (TweetRecommender/Experiment.cs:64-134, ten threads of it: Program.cs:11) is thousands of
+ * ego-network-sized graphs, each built once, asked ONE Recommendation(seed, d, nIteration) and evaluated against its fold's
+ * test set.  Entry g of the batch is exactly
+ *     rwr_graph_create(graphs[g]) ; rwr_recommend_eval(seeds[g], d, n_iter, test set g) ; rwr_graph_destroy
+ * -- the same arrays, the same arithmetic, bit for bit -- but graphs that fit the one-launch build and the one-launch call
+ * (up to 6144 nodes / 4096 items / 65536 links) share ONE build launch, ONE iteration launch and ONE evaluation launch for
+ * the whole batch (a workgroup per graph) and three synchronisations in total; larger graphs of the batch take the calls
+ * above one by one.  test set g = test_ids[test_ptr[g] .. test_ptr[g+1]); n_hits / sum_precision / list_len (optional)
+ * have `count` entries.  opts as for rwr_graph_create (device, mode). */
+typedef struct rwr_graph_desc {
+    int32_t n_nodes;
+    int32_t reserved0;
+    const int64_t *node_id;        /* [n_nodes] */
+    const uint8_t *node_type;      /* [n_nodes] */
+    const int64_t *rowptr;         /* [n_nodes + 1] */
+    const int32_t *dst;            /* [rowptr[n_nodes]] */
+    const uint8_t *etype;
+    const double *w;
+} rwr_graph_desc;
+int32_t rwr_eval_graphs(int32_t count, const rwr_graph_desc *graphs, const int32_t *seeds, float d, int32_t n_iter,
+                        const int64_t *test_ptr, const int64_t *test_ids, const rwr_opts *opts, int64_t *n_hits,
+                        double *sum_precision, int64_t *list_len);
+
 /* Batch entry (an addition: the reference creates a fresh Model per call, Recommender.cs:16,
  * so seeds are independent and batching is semantically free).  top_n must be >= 1.
  * ids/scores are K x top_n row-major; counts[k] = entries valid in row k (the rest of the

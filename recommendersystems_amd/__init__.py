@@ -6,7 +6,7 @@ reference's ``Recommenders.RWRBased`` (ChangUk/RecommenderSystems).
   rwr_based.py   host-side mirror of Graph / Model / Recommender / Node / ForwardLink / enums
   synth.py       deterministic integer-only synthetic bipartite graphs
 """
-from .rwr_based import EdgeType, ForwardLink, Graph, Model, Node, NodeType, Recommender  # noqa: F401
+from .rwr_based import EdgeType, EvaluateGraphs, ForwardLink, Graph, Model, Node, NodeType, Recommender  # noqa: F401
 from ._lib import RwrError  # noqa: F401
 
-__all__ = ["EdgeType", "ForwardLink", "Graph", "Model", "Node", "NodeType", "Recommender", "RwrError"]
+__all__ = ["EdgeType", "EvaluateGraphs", "ForwardLink", "Graph", "Model", "Node", "NodeType", "Recommender", "RwrError"]

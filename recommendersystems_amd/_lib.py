@@ -19,7 +19,7 @@ RWR_RUN_ITERATIONS, RWR_RUN_THRESHOLD, RWR_RUN_DEFAULT_THRESHOLD = 0, 1, 2
 EXPORTS = [
     "rwr_version", "rwr_device_count", "rwr_last_error",
     "rwr_graph_create", "rwr_graph_update_links", "rwr_graph_destroy", "rwr_graph_size", "rwr_graph_get_normalized",
-    "rwr_recommend", "rwr_recommend_eval", "rwr_recommend_eval_batch", "rwr_recommend_batch", "rwr_model_run", "rwr_model_deliver",
+    "rwr_recommend", "rwr_recommend_eval", "rwr_recommend_eval_batch", "rwr_eval_graphs", "rwr_recommend_batch", "rwr_model_run", "rwr_model_deliver",
     "rwr_part_begin", "rwr_part_step", "rwr_part_local_step", "rwr_part_finish_step", "rwr_part_rank",
     "rwr_get_stats", "rwr_reset_stats",
 ]
@@ -29,6 +29,12 @@ class rwr_opts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("mode", C.c_int32),
                 ("tile_seeds", C.c_int32), ("tile_group", C.c_int32), ("profile", C.c_int32),
                 ("workspace_bytes", C.c_int64), ("seed_row_kernel", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class rwr_graph_desc(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("reserved0", C.c_int32), ("node_id", C.POINTER(C.c_int64)),
+                ("node_type", C.POINTER(C.c_uint8)), ("rowptr", C.POINTER(C.c_int64)), ("dst", C.POINTER(C.c_int32)),
+                ("etype", C.POINTER(C.c_uint8)), ("w", C.POINTER(C.c_double))]
 
 
 class rwr_stats(C.Structure):
@@ -84,6 +90,9 @@ def load():
     lib.rwr_recommend_eval_batch.restype = C.c_int32
     lib.rwr_recommend_eval_batch.argtypes = [C.c_void_p, p(C.c_int32), C.c_int32, C.c_float, C.c_int32, p(C.c_int64),
                                              p(C.c_int64), p(C.c_int64), p(C.c_double), p(C.c_int64)]
+    lib.rwr_eval_graphs.restype = C.c_int32
+    lib.rwr_eval_graphs.argtypes = [C.c_int32, p(rwr_graph_desc), p(C.c_int32), C.c_float, C.c_int32, p(C.c_int64), p(C.c_int64),
+                                    p(rwr_opts), p(C.c_int64), p(C.c_double), p(C.c_int64)]
     lib.rwr_recommend_batch.restype = C.c_int32
     lib.rwr_recommend_batch.argtypes = [C.c_void_p, p(C.c_int32), C.c_int32, C.c_float, C.c_int32, C.c_int32,
                                         p(C.c_int64), p(C.c_double), p(C.c_int32)]

@@ -2,6 +2,7 @@
 // usable gfx950 device every compute entry fails with RWR_E_NO_DEVICE.
 #include <stdarg.h>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <vector>
 #include <stdlib.h>
@@ -29,6 +30,35 @@ static int usable_devices()
         return 0;
     }
     return n;
+}
+
+// "is device d a gfx950" -- asked once per device and process: hipGetDeviceProperties goes to the driver under a runtime-wide
+// lock, and the reference's harness creates a graph per fold and methodology from ten threads (Program.cs:11)
+#ifdef RWR_EXPERIMENTS
+static double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+#endif
+static int32_t check_gfx950(int device)
+{
+    static std::mutex mu;
+    static int state[64];            // 0 unknown, 1 gfx950, 2 something else
+    static char names[64][64];
+    if (device < 0 || device >= 64) { set_error("device %d out of range", device); return RWR_E_NO_DEVICE; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (state[device] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error("hipGetDeviceProperties failed"); return RWR_E_HIP; }
+        snprintf(names[device], sizeof(names[device]), "%s", prop.gcnArchName);
+        state[device] = strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 2;
+    }
+    if (state[device] != 1) {
+        set_error("device %d is %s; librwr is built for gfx950 only", device, names[device]);
+        return RWR_E_NO_DEVICE;
+    }
+    return RWR_OK;
 }
 
 // Makes the graph's device current for the duration of one entry point and gives the caller's device back on every
@@ -135,6 +165,34 @@ inline int pool_class(size_t bytes, size_t *size)
     *size = sz;
     return c;
 }
+// In front of the shared cache, a cache per host thread that needs no lock: the harness's ten threads (Program.cs:11) each
+// build and drop graphs of ~30 device arrays, and ten threads taking one mutex a thousand times per call spent more time
+// in the mutex's slow path than in the rest of the library (measured: 25 ns per operation alone, 3.5 us with ten threads).
+// A thread keeps what it frees, up to TL_CAP bytes / TL_PER_CLASS blocks per size; the rest, and everything it holds when it
+// ends, goes to the shared cache.
+constexpr size_t TL_CAP = 256ull << 20;
+constexpr size_t TL_PER_CLASS = 512;
+struct ThreadCache {
+    int dev = -1;
+    std::vector<void *> blocks[POOL_CLASSES];
+    size_t bytes = 0;
+    void flush()
+    {
+        if (dev < 0 || dev >= POOL_DEVICES) return;
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        size_t size = POOL_MIN;
+        for (int c = 0; c < POOL_CLASSES; ++c, size <<= 1) {
+            for (void *p : blocks[c]) {
+                g_pool[dev].free_blocks[c].push_back(p);          // (may exceed POOL_CAP: nothing is freed from a destructor)
+                g_pool[dev].cached += size;
+            }
+            blocks[c].clear();
+        }
+        bytes = 0;
+    }
+    ~ThreadCache() { flush(); }
+};
+thread_local ThreadCache tl_cache;
 }  // namespace
 
 void *pool_alloc(size_t bytes, size_t *got)
@@ -148,7 +206,14 @@ void *pool_alloc(size_t bytes, size_t *got)
     const int c = pool_class(bytes, &size);
     *got = size;
     int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < POOL_DEVICES) {
+    const bool dev_ok = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < POOL_DEVICES;
+    if (dev_ok && tl_cache.dev == dev && !tl_cache.blocks[c].empty()) {
+        p = tl_cache.blocks[c].back();
+        tl_cache.blocks[c].pop_back();
+        tl_cache.bytes -= size;
+        return p;
+    }
+    if (dev_ok) {
         std::lock_guard<std::mutex> lk(g_pool_mutex);
         auto &fl = g_pool[dev].free_blocks[c];
         if (!fl.empty()) {
@@ -163,6 +228,7 @@ void *pool_alloc(size_t bytes, size_t *got)
     (void)hipGetLastError();
     std::vector<void *> drop;
     if (dev >= 0 && dev < POOL_DEVICES) {
+        if (tl_cache.dev == dev) tl_cache.flush();             // (this thread's own cache too; other threads' stay with them)
         std::lock_guard<std::mutex> lk(g_pool_mutex);
         for (auto &fl : g_pool[dev].free_blocks) { drop.insert(drop.end(), fl.begin(), fl.end()); fl.clear(); }
         g_pool[dev].cached = 0;
@@ -180,6 +246,12 @@ void pool_free(void *p, size_t got)
         // (the block belongs to the current device: every entry point binds the handle's device before it touches memory)
         size_t size = 0;
         const int c = pool_class(got, &size);
+        if (tl_cache.dev != dev && tl_cache.bytes == 0) tl_cache.dev = dev;
+        if (tl_cache.dev == dev && tl_cache.bytes + size <= TL_CAP && tl_cache.blocks[c].size() < TL_PER_CLASS) {
+            tl_cache.blocks[c].push_back(p);
+            tl_cache.bytes += size;
+            return;
+        }
         std::lock_guard<std::mutex> lk(g_pool_mutex);
         if (g_pool[dev].cached + size <= POOL_CAP) {
             g_pool[dev].free_blocks[c].push_back(p);
@@ -273,12 +345,7 @@ int32_t rwr_graph_create(int32_t n, const int64_t *node_id, const uint8_t *node_
     };
     rwr::DeviceGuard dev_guard(g->device);
     if (dev_guard.rc != RWR_OK) return fail(dev_guard.rc);
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, g->device) != hipSuccess) { set_error("hipGetDeviceProperties failed"); return fail(RWR_E_HIP); }
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        set_error("device %d is %s; librwr is built for gfx950 only", g->device, prop.gcnArchName);
-        return fail(RWR_E_NO_DEVICE);
-    }
+    if ((rc = check_gfx950(g->device)) != RWR_OK) return fail(rc);
     // the seed-row chain (stream2) is latency-bound and must not queue behind the SpMM's half-million
     // workgroups: give its stream the highest dispatch priority
     HandleKit kit;
@@ -367,6 +434,224 @@ int32_t rwr_graph_get_normalized(rwr_graph *g, double *w_out, uint8_t *dangling_
     if (w_out && g->nnz_raw > 0)
         RWR_HIP(hipMemcpy(w_out, g->w_norm_raw.p, sizeof(double) * (size_t)g->nnz_raw, hipMemcpyDeviceToHost));
     if (dangling_out) RWR_HIP(hipMemcpy(dangling_out, g->dangling.p, (size_t)g->n, hipMemcpyDeviceToHost));
+    return RWR_OK;
+}
+
+int32_t rwr_eval_graphs(int32_t count, const rwr_graph_desc *graphs, const int32_t *seeds, float d, int32_t n_iter,
+                        const int64_t *test_ptr, const int64_t *test_ids, const rwr_opts *opts, int64_t *n_hits,
+                        double *sum_precision, int64_t *list_len)
+{
+    g_err[0] = 0;
+#ifdef RWR_EXPERIMENTS
+    const double t_enter = now_ms();
+    double t_kit = 0, t_loop = 0;
+#endif
+    if (count < 0 || (count > 0 && (!graphs || !seeds || !test_ptr || !n_hits || !sum_precision))) {
+        set_error("rwr_eval_graphs: bad argument");
+        return RWR_E_INVALID;
+    }
+    if (count == 0) return RWR_OK;
+    if (n_iter < 0) n_iter = 0;
+    for (int32_t i = 0; i < count; ++i) {
+        const rwr_graph_desc &D = graphs[i];
+        if (D.n_nodes <= 0 || !D.node_id || !D.node_type || !D.rowptr) {
+            set_error("rwr_eval_graphs: graph %d: n_nodes must be > 0 and node_id/node_type/rowptr non-NULL", i);
+            return RWR_E_INVALID;
+        }
+        if (D.rowptr[0] != 0) { set_error("rwr_eval_graphs: graph %d: rowptr[0] must be 0", i); return RWR_E_INVALID; }
+        for (int32_t q = 0; q < D.n_nodes; ++q)
+            if (D.rowptr[q + 1] < D.rowptr[q]) { set_error("rwr_eval_graphs: graph %d: rowptr decreases at node %d", i, q); return RWR_E_INVALID; }
+        if (D.rowptr[D.n_nodes] > 0 && (!D.dst || !D.etype || !D.w)) {
+            set_error("rwr_eval_graphs: graph %d: dst/etype/w must be non-NULL when there are links", i);
+            return RWR_E_INVALID;
+        }
+        if (seeds[i] < 0 || seeds[i] >= D.n_nodes) { set_error("graph %d: seed %d is outside [0, %d)", i, seeds[i], D.n_nodes); return RWR_E_RANGE; }
+        if (test_ptr[i + 1] < test_ptr[i] || test_ptr[i + 1] - test_ptr[i] > 0x7FFFFFFF) {
+            set_error("rwr_eval_graphs: test_ptr must be non-decreasing (graph %d)", i);
+            return RWR_E_INVALID;
+        }
+    }
+    if (test_ptr[count] > test_ptr[0] && !test_ids) { set_error("rwr_eval_graphs: test_ids is NULL"); return RWR_E_INVALID; }
+    for (int32_t i = 0; i < count; ++i) { n_hits[i] = 0; sum_precision[i] = 0.0; if (list_len) list_len[i] = 0; }
+
+    // a graph that the one-launch paths cannot take goes through the public single-graph calls
+    auto one_by_one = [&](int32_t i) -> int32_t {
+        const rwr_graph_desc &D = graphs[i];
+        rwr_graph *g1 = nullptr;
+        int32_t rc = rwr_graph_create(D.n_nodes, D.node_id, D.node_type, D.rowptr, D.dst, D.etype, D.w, opts, &g1);
+        if (rc == RWR_OK)
+            rc = rwr_recommend_eval(g1, seeds[i], d, n_iter, test_ids ? test_ids + test_ptr[i] : nullptr, test_ptr[i + 1] - test_ptr[i],
+                                    n_hits + i, sum_precision + i, list_len ? list_len + i : nullptr);
+        if (rc != RWR_OK) {
+            char msg[600];
+            snprintf(msg, sizeof(msg), "%s", g_err);
+            set_error("graph %d of the batch: %s", i, msg);
+        }
+        if (g1) (void)rwr_graph_destroy(g1);
+        return rc;
+    };
+    std::vector<int32_t> fast, slow;
+    const bool d_ok = (double)d >= 0.0 && (double)d <= 1.0;
+    for (int32_t i = 0; i < count; ++i) {
+        const rwr_graph_desc &D = graphs[i];
+        (d_ok && rwr::graph_fits_small_build(D.n_nodes, D.rowptr[D.n_nodes]) ? fast : slow).push_back(i);
+    }
+    if (!fast.empty()) {
+        // the batch's stream comes from the handle pool (rwr_graph_create's); every graph of the batch works on it
+        const int ndev = usable_devices();
+        if (ndev <= 0) { set_error("no usable HIP device (librwr has no CPU fallback)"); return RWR_E_NO_DEVICE; }
+        rwr_opts o{};
+        o.struct_size = sizeof(rwr_opts);
+        o.device = -1;
+        o.mode = -1;
+        if (opts) {
+            size_t sz = opts->struct_size > 0 ? (size_t)opts->struct_size : sizeof(rwr_opts);
+            if (sz > sizeof(rwr_opts)) sz = sizeof(rwr_opts);
+            memcpy(&o, opts, sz);
+        }
+        if (o.device < 0) {
+            const char *e = getenv("RWR_DEVICE");
+            if (e && *e) o.device = atoi(e);
+            else { int cur = 0; if (hipGetDevice(&cur) != hipSuccess) cur = 0; o.device = cur; }
+        }
+        if (o.mode < 0) o.mode = RWR_MODE_EXACT;
+        if (o.device >= ndev) { set_error("rwr_eval_graphs: device %d requested but only %d visible", o.device, ndev); return RWR_E_NO_DEVICE; }
+        if (o.mode != RWR_MODE_EXACT) { set_error("rwr_eval_graphs: unknown mode %d (the only arithmetic mode is RWR_MODE_EXACT = 0)", o.mode); return RWR_E_INVALID; }
+        rwr::DeviceGuard dev_guard(o.device);
+        if (dev_guard.rc != RWR_OK) return dev_guard.rc;
+        RWR_TRY(check_gfx950(o.device));
+        HandleKit kit;
+        if (!kit_take(o.device, &kit)) {     // (a full set, as rwr_graph_create makes one, so that the pool keeps it afterwards)
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            if (hipStreamCreateWithFlags(&kit.stream, hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithPriority(&kit.stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+                hipStreamCreateWithPriority(&kit.stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+                hipEventCreateWithFlags(&kit.ev_h0, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&kit.ev_h1, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&kit.ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&kit.ev_join, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreate(&kit.ev_a) != hipSuccess || hipEventCreate(&kit.ev_b) != hipSuccess) {
+                set_error("stream/event creation failed: %s", hipGetErrorString(hipGetLastError()));
+                kit_destroy(kit);
+                return RWR_E_HIP;
+            }
+        }
+        kit.device = o.device;
+        rwr::multi_pins_acquire();
+#ifdef RWR_EXPERIMENTS
+        t_kit = now_ms();
+#endif
+        constexpr int32_t CHUNK = 256;                     // graphs per launch (a workgroup each)
+        int32_t rc = RWR_OK;
+        std::vector<rwr_graph *> gs;
+        auto drop = [&]() {
+            for (rwr_graph *g : gs) delete g;              // (device buffers go back to the pool; nothing else is owned)
+            gs.clear();
+        };
+        for (size_t c0 = 0; c0 < fast.size() && rc == RWR_OK; c0 += CHUNK) {
+            const int32_t nc = (int32_t)std::min<size_t>(CHUNK, fast.size() - c0);
+            std::vector<rwr_graph_desc> descs((size_t)nc);
+            for (int32_t q = 0; q < nc; ++q) {
+                const int32_t i = fast[c0 + q];
+                descs[q] = graphs[i];
+                rwr_graph *g = new (std::nothrow) rwr_graph();
+                if (!g) { set_error("out of host memory"); rc = RWR_E_NOMEM; break; }
+                g->opts = o;
+                g->device = o.device;
+                g->n = graphs[i].n_nodes;
+                g->nnz_raw = graphs[i].rowptr[graphs[i].n_nodes];
+                g->stream = kit.stream;
+                g->borrowed = 1;
+                g->stats.struct_size = sizeof(rwr_stats);
+                gs.push_back(g);
+            }
+            if (rc != RWR_OK) break;
+#ifdef RWR_EXPERIMENTS
+            static const bool mt_on = [] { const char *e = getenv("RWR_X_MULTI_TIMING"); return e && atoi(e) != 0; }();
+            const double q0 = now_ms();
+            double q1 = 0, q2 = 0, q3 = 0;
+#endif
+            rc = rwr::graphs_build_multi(gs.data(), nc, descs.data(), kit.stream);
+#ifdef RWR_EXPERIMENTS
+            q1 = now_ms();
+#endif
+            if (rc != RWR_OK) {
+                // (the message names the position inside the chunk: translate to the caller's numbering)
+                break;
+            }
+            // the one-launch call takes the graphs that pass its own limits (items, links, the seed's in-list)
+            std::vector<rwr_graph *> run;
+            std::vector<int32_t> run_seed, run_at;
+            for (int32_t q = 0; q < nc; ++q) {
+                const int32_t i = fast[c0 + q];
+                rwr_graph *g = gs[q];
+                if (g->n_items == 0) continue;             // (no candidates: hits 0, empty list)
+                if (g->nonneg && rwr::small_path_ok(g) && rwr::small_path_seed_ok(g, seeds[i])) {
+                    run.push_back(g);
+                    run_seed.push_back(seeds[i]);
+                    run_at.push_back(i);
+                } else {
+                    slow.push_back(i);
+                }
+            }
+            if (!run.empty()) {
+                const int32_t nr = (int32_t)run.size();
+                rwr::DevBuf<uint8_t> args_keep;            // (lives until eval_ranked_multi has synchronised the stream)
+                rc = rwr::recommend_small_multi(run.data(), run_seed.data(), nr, (double)d, n_iter, kit.stream, args_keep);
+#ifdef RWR_EXPERIMENTS
+                q2 = now_ms();
+#endif
+                if (rc == RWR_OK) {
+                    // HashSet<long> semantics per test set (Experiment.cs:124): sorted, duplicates dropped
+                    std::vector<int64_t> ts, tp((size_t)nr + 1, 0), hits((size_t)nr), lens((size_t)nr);
+                    std::vector<double> sums((size_t)nr);
+                    for (int32_t q = 0; q < nr; ++q) {
+                        const int32_t i = run_at[q];
+                        const size_t at = ts.size();
+                        if (test_ptr[i + 1] > test_ptr[i]) ts.insert(ts.end(), test_ids + test_ptr[i], test_ids + test_ptr[i + 1]);
+                        std::sort(ts.begin() + (long)at, ts.end());
+                        ts.erase(std::unique(ts.begin() + (long)at, ts.end()), ts.end());
+                        tp[(size_t)q + 1] = (int64_t)ts.size();
+                    }
+                    rc = rwr::eval_ranked_multi(run.data(), nr, tp.data(), ts.data(), hits.data(), sums.data(), lens.data(), kit.stream);
+                    if (rc == RWR_OK)
+                        for (int32_t q = 0; q < nr; ++q) {
+                            const int32_t i = run_at[q];
+                            n_hits[i] = hits[q];
+                            sum_precision[i] = sums[q];
+                            if (list_len) list_len[i] = lens[q];
+                        }
+                }
+                if (rc != RWR_OK) (void)hipStreamSynchronize(kit.stream);   // (nothing may be in flight when the tables are released)
+            }
+#ifdef RWR_EXPERIMENTS
+            q3 = now_ms();
+#endif
+            drop();
+#ifdef RWR_EXPERIMENTS
+            if (mt_on) fprintf(stderr, "[multi] %d graphs: build %.0f us, call enqueue %.0f, evaluation (incl. wait) %.0f, release %.0f\n", nc,
+                               1e3 * (q1 - q0), 1e3 * (q2 - q1), 1e3 * (q3 - q2), 1e3 * (now_ms() - q3));
+#endif
+        }
+        drop();
+#ifdef RWR_EXPERIMENTS
+        t_loop = now_ms();
+#endif
+        (void)hipStreamSynchronize(kit.stream);
+        rwr::multi_pins_release();
+        kit_give(kit);
+#ifdef RWR_EXPERIMENTS
+        {
+            static const bool mt_on2 = [] { const char *e = getenv("RWR_X_MULTI_TIMING"); return e && atoi(e) != 0; }();
+            if (mt_on2) fprintf(stderr, "[multi call] entry->kit %.0f us, chunks %.0f, tail %.0f\n", 1e3 * (t_kit - t_enter), 1e3 * (t_loop - t_kit),
+                                1e3 * (now_ms() - t_loop));
+        }
+#endif
+        if (rc != RWR_OK) return rc;
+    }
+    std::sort(slow.begin(), slow.end());
+    for (int32_t i : slow) RWR_TRY(one_by_one(i));
     return RWR_OK;
 }
 

@@ -12,6 +12,8 @@
 #include "sort_small.h"
 
 #include <chrono>
+#include <mutex>
+#include <vector>
 #include <cstdlib>
 #include <cstring>
 
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(256) void k_stage_out(int32_t n, const int64_t *__r
 // arrays (tests/test_gpu_parity.py: test_build_graph_bitwise, the golden fixtures, the hypothesis graphs, incremental rebuilds).
 struct BuildSmallArgs {
     int32_t n, n_items, first, do_stage_in;
+    int32_t zero_flags, pad0;        // the kernel clears the flag words itself (batch builds: no memset per graph)
     int64_t m;
     const uint8_t *stage; StageLayout L;
     int64_t *node_id; uint8_t *node_type; int64_t *rowptr; int32_t *dst; uint8_t *etype; double *w_raw;
@@ -406,7 +409,7 @@ struct BuildSmallArgs {
 #endif
 constexpr int BS_CAP = 1024;                     // links per LDS tile and wave of the row pass
 constexpr int BS_ROW_WAVES = 8;                  // waves that take part in the row pass (their tiles share the LDS with the sort's tables)
-__global__ __launch_bounds__(SMALL_SORT_THREADS) void k_build_small(BuildSmallArgs a)
+__device__ __forceinline__ void build_small_body(const BuildSmallArgs &a)
 {
     constexpr int NT = SMALL_SORT_THREADS;
     __shared__ SmallSortLds sortlds;
@@ -418,6 +421,10 @@ __global__ __launch_bounds__(SMALL_SORT_THREADS) void k_build_small(BuildSmallAr
     const int32_t n = a.n;
     const int64_t m = a.m;
     BS_STAMP(0)
+    if (a.zero_flags) {
+        if (tid < 4) a.flags[tid] = 0;
+        __syncthreads();
+    }
     // ---- the staging copy's arrays (first build only; an incremental rebuild patches the resident arrays)
     if (a.do_stage_in) {
         const int64_t work = (m > (int64_t)n + 1) ? m : (int64_t)n + 1;
@@ -529,6 +536,12 @@ __global__ __launch_bounds__(SMALL_SORT_THREADS) void k_build_small(BuildSmallAr
     }
     BS_STAMP(7)
 }
+__global__ __launch_bounds__(SMALL_SORT_THREADS) void k_build_small(BuildSmallArgs a) { build_small_body(a); }
+// a batch of ego-network-sized graphs (rwr_eval_graphs): one workgroup per graph, ONE launch for all of them
+__global__ __launch_bounds__(SMALL_SORT_THREADS) void k_build_small_multi(const BuildSmallArgs *__restrict__ args)
+{
+    build_small_body(args[blockIdx.x]);
+}
 
 static int bit_length(uint64_t v)
 {
@@ -549,8 +562,8 @@ static const bool bt_on = [] { const char *e = RWR_TUNE_ENV("RWR_BUILD_TIMING");
 
 // uploads the RAW lists (they stay resident: the exclusion list reads them, Recommender.cs:20-24, and an incremental
 // rebuild re-derives everything else from them), then derives the walk's data
-int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_type, const int64_t *rowptr,
-                    const int32_t *dst, const uint8_t *etype, const double *w)
+static int32_t graph_build_upload(rwr_graph *g, const int64_t *node_id, const uint8_t *node_type, const int64_t *rowptr,
+                                  const int32_t *dst, const uint8_t *etype, const double *w)
 {
     const int32_t n = g->n;
     const int64_t m = g->nnz_raw;
@@ -608,8 +621,10 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
             memcpy(st + L.dst, dst, 4 * (size_t)m);
             memcpy(st + L.et, etype, (size_t)m);
         }
-        RWR_TRY(g->d_stage.ensure(L.total + 8));
-        RWR_HIP(hipMemcpyAsync(g->d_stage.p, st, L.total, hipMemcpyHostToDevice, s));
+        if (!g->stage_dev_ext) {        // (a batch copies all its graphs' slots with one transfer: graphs_build_multi)
+            RWR_TRY(g->d_stage.ensure(L.total + 8));
+            RWR_HIP(hipMemcpyAsync(g->d_stage.p, st, L.total, hipMemcpyHostToDevice, s));
+        }
         g->stage_pending = 1;           // (k_build_small unpacks the copy: graph_derive)
     } else {
         RWR_HIP(hipMemcpyAsync(g->node_id.p, node_id, sizeof(int64_t) * n, hipMemcpyHostToDevice, s));
@@ -622,6 +637,13 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
         }
     }
     BT("H2D enqueue");
+    return RWR_OK;
+}
+
+int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_type, const int64_t *rowptr,
+                    const int32_t *dst, const uint8_t *etype, const double *w)
+{
+    RWR_TRY(graph_build_upload(g, node_id, node_type, rowptr, dst, etype, w));
     return graph_derive(g, true);
 }
 
@@ -687,12 +709,91 @@ static int32_t derive_finish(rwr_graph *g, const int *h_flags, hipEvent_t e0, hi
     }
     BT("D2H in_ptr/dangling + bins");
     float ms = 0.f;
-    RWR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (e0 && e1) RWR_HIP(hipEventElapsedTime(&ms, e0, e1));      // (a batch build is not timed per graph)
     g->stats.build_ms = ms;
     g->stats.nnz = g->nnz;
     g->stats.uniform = g->uniform;
     g->stats.uniform_path = g->vf;
     return RWR_OK;
+}
+
+// ---- the one-launch build of an ego-network-sized graph, in two halves around its launch: a single graph launches
+// k_build_small in between (graph_derive), a batch of graphs one k_build_small_multi for all of them (graphs_build_multi)
+struct SmallBuild {
+    DevBuf<int32_t> esrc;
+    DevBuf<uint32_t> skey, skey2, sval, sval2, ival, ival2;
+    DevBuf<uint64_t> ikey, ikey2;
+    DevBuf<int> flags;
+    BuildSmallArgs a{};
+};
+static bool small_build_ok(const rwr_graph *g)
+{
+    static const bool by_degree = [] { const char *e = RWR_TUNE_ENV("RWR_ROW_ORDER"); return !e || atoi(e) == 0; }();
+    return g->staged && g->sm_stage && g->n <= STAGE_MAX_N && g->nnz_raw <= STAGE_MAX_M && by_degree;
+}
+static int32_t small_build_begin(rwr_graph *g, bool first, SmallBuild &b)
+{
+    const int32_t n = g->n;
+    const int64_t m = g->nnz_raw;
+    // the (key, value) buffers serve the link sort (m entries) AND, afterwards, the row-order / item sorts (n entries)
+    const size_t kv = (size_t)(m > (int64_t)n ? m : (int64_t)n);
+    RWR_TRY(b.esrc.alloc(m));
+    RWR_TRY(b.skey.alloc(kv));
+    RWR_TRY(b.skey2.alloc(kv));
+    RWR_TRY(b.sval.alloc(kv));
+    RWR_TRY(b.sval2.alloc(kv));
+    RWR_TRY(b.flags.alloc(4));
+    RWR_TRY(b.ikey.alloc(n));
+    RWR_TRY(b.ikey2.alloc(n));
+    RWR_TRY(b.ival.alloc(n));
+    RWR_TRY(b.ival2.alloc(n));
+    RWR_TRY(g->in_src.ensure((size_t)m + 64));
+    RWR_TRY(g->in_w.ensure((size_t)(m > 0 ? m : 1)));
+    BuildSmallArgs &a = b.a;
+    a = BuildSmallArgs{};
+    a.n = n; a.n_items = g->n_items; a.first = first ? 1 : 0; a.do_stage_in = g->stage_pending ? 1 : 0; a.m = m;
+    a.zero_flags = 1;
+    a.stage = g->stage_dev_ext ? g->stage_dev_ext : g->d_stage.p; a.L = stage_layout(n, m);
+    a.node_id = g->node_id.p; a.node_type = g->node_type.p; a.rowptr = g->rowptr.p; a.dst = g->dst.p; a.etype = g->etype.p;
+    a.w_raw = g->w_raw.p; a.w_norm = g->w_norm_raw.p; a.esrc = b.esrc.p; a.skey = b.skey.p; a.skey2 = b.skey2.p; a.sval = b.sval.p;
+    a.sval2 = b.sval2.p; a.dangling = g->dangling.p; a.w_src = g->w_src.p; a.flags = b.flags.p; a.in_ptr = g->in_ptr.p;
+    a.in_src = g->in_src.p; a.in_w = g->in_w.p; a.row_order = g->row_order.p; a.row_order_x = g->row_order_x.p;
+    a.item_rows = g->item_rows.p; a.item_order = g->item_order.p; a.ikey = b.ikey.p; a.ikey2 = b.ikey2.p; a.ival = b.ival.p;
+    a.ival2 = b.ival2.p;
+    a.order_mode = 0;
+    a.top = (uint32_t)m;                                   // (any bound of the in-degrees gives the same order)
+    a.top_bits = bit_length((uint64_t)m) > 0 ? bit_length((uint64_t)m) : 1;
+    a.ptop_bits = a.top_bits > 31 ? 31 : a.top_bits;
+    a.ptop = a.top_bits > 31 ? 0x7FFFFFFFu : a.top;
+    a.n_bits = bit_length((uint64_t)n);
+    a.id_key_top = g->id_key_top; a.id_key_bits = g->id_key_bits;
+    a.pin_out = g->sm_out ? g->sm_out : static_cast<uint8_t *>(g->sm_stage) + STAGE_OUT_OFF;
+    a.stamps = nullptr;
+    return RWR_OK;
+}
+// after the stream the build ran on has been synchronised
+static int32_t small_build_end(rwr_graph *g, SmallBuild &b, hipEvent_t e0, hipEvent_t e1)
+{
+    static const int vf_env_s = [] { const char *e = getenv("RWR_VALUE_FREE"); return e ? atoi(e) : 1; }();
+    const int32_t n = g->n;
+    const uint8_t *pin = b.a.pin_out;
+    int h_flags[4];
+    g->stage_pending = 0;
+    g->h_in_ptr.resize((size_t)n + 1);
+    g->h_dangling.resize((size_t)n);
+    const int64_t nnz_s = reinterpret_cast<const int64_t *>(pin)[0];
+    memcpy(h_flags, pin + 8, sizeof(h_flags));
+    memcpy(g->h_in_ptr.data(), pin + 32, sizeof(int64_t) * ((size_t)n + 1));
+    memcpy(g->h_dangling.data(), pin + 32 + 8 * ((size_t)n + 1), (size_t)n);
+    if (h_flags[1]) {
+        set_error("rwr_graph_create: a link targets a node outside [0, %d)", n);
+        return RWR_E_RANGE;
+    }
+    g->nnz = nnz_s;
+    g->uniform = h_flags[0] ? 0 : 1;
+    g->nonneg = h_flags[3] ? 0 : 1;
+    g->vf = (g->uniform && g->nonneg && vf_env_s) ? 1 : 0;   // (in_w stays: small.hip reads it)
+    return derive_finish(g, h_flags, e0, e1);
 }
 
 // Graph.buildGraph + transpose + processing orders, from the device-resident raw lists
@@ -709,6 +810,38 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     const int32_t n_items = g->n_items;
     hipStream_t s = g->stream;
     double bt_t = bt_now();
+    hipEvent_t e0 = g->ev_a, e1 = g->ev_b;
+    if (small_build_ok(g)) {
+        // ego-network-sized graph: the whole device-side build is ONE launch (k_build_small) and one synchronisation
+        SmallBuild b;
+        RWR_TRY(small_build_begin(g, first, b));
+        BT("derive allocs");
+#ifdef RWR_EXPERIMENTS
+        DevBuf<unsigned long long> stamps_d;
+        if (bt_on) { RWR_TRY(stamps_d.alloc(8)); b.a.stamps = stamps_d.p; }
+#endif
+        RWR_HIP(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(k_build_small, dim3(1), dim3(SMALL_SORT_THREADS), 0, s, b.a);
+        RWR_HIP(hipGetLastError());
+        RWR_HIP(hipEventRecord(e1, s));
+        BT("enqueue one-launch build");
+        RWR_HIP(hipStreamSynchronize(s));                      // the ONE synchronisation of an ego-network-sized build
+        BT("sync (whole build)");
+#ifdef RWR_EXPERIMENTS
+        if (bt_on) {
+            unsigned long long hs[8];
+            RWR_HIP(hipMemcpy(hs, stamps_d.p, sizeof(hs), hipMemcpyDeviceToHost));
+            unsigned long long rp[16];
+            (void)hipMemcpyFromSymbol(rp, HIP_SYMBOL(rp_dbg), sizeof(rp));
+            fprintf(stderr, "[build] row pass of group 0 (us): setup %.1f sweep1 %.1f sweep2 %.1f; started %.1f after stage 1\n", (rp[1] - rp[0]) / 100.0,
+                    (rp[2] - rp[1]) / 100.0, (rp[3] - rp[2]) / 100.0, (rp[0] - hs[1]) / 100.0);
+            fprintf(stderr, "[build] k_build_small stages (us): unpack %.1f rows %.1f linksort %.1f in_ptr+gather %.1f orders %.1f items %.1f out %.1f\n",
+                    (hs[1] - hs[0]) / 100.0, (hs[2] - hs[1]) / 100.0, (hs[3] - hs[2]) / 100.0, (hs[4] - hs[3]) / 100.0, (hs[5] - hs[4]) / 100.0,
+                    (hs[6] - hs[5]) / 100.0, (hs[7] - hs[6]) / 100.0);
+        }
+#endif
+        return small_build_end(g, b, e0, e1);
+    }
     DevBuf<int32_t> esrc;
     DevBuf<uint32_t> skey, skey2, sval, sval2;
     DevBuf<uint8_t> temp;
@@ -729,81 +862,8 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     RWR_HIP(hipMemsetAsync(flags.p, 0, sizeof(h_flags), s));
 
     BT("derive allocs");
-    hipEvent_t e0 = g->ev_a, e1 = g->ev_b;
     RWR_HIP(hipEventRecord(e0, s));
 
-    const char *om_s = RWR_TUNE_ENV("RWR_ROW_ORDER");
-    const bool fused = g->staged && g->sm_stage && n <= STAGE_MAX_N && m <= STAGE_MAX_M && (!om_s || atoi(om_s) == 0);
-    if (fused) {
-        // ego-network-sized graph: the whole device-side build is ONE launch (k_build_small) and one synchronisation
-        static const int vf_env_s = [] { const char *e = getenv("RWR_VALUE_FREE"); return e ? atoi(e) : 1; }();
-        DevBuf<uint64_t> ikey_s, ikey2_s;
-        DevBuf<uint32_t> ival_s, ival2_s;
-        RWR_TRY(ikey_s.alloc(n));
-        RWR_TRY(ikey2_s.alloc(n));
-        RWR_TRY(ival_s.alloc(n));
-        RWR_TRY(ival2_s.alloc(n));
-        RWR_TRY(g->in_src.ensure((size_t)m + 64));
-        RWR_TRY(g->in_w.ensure((size_t)(m > 0 ? m : 1)));
-        uint8_t *pin = static_cast<uint8_t *>(g->sm_stage) + STAGE_OUT_OFF;
-        BuildSmallArgs a{};
-        a.n = n; a.n_items = n_items; a.first = first ? 1 : 0; a.do_stage_in = g->stage_pending ? 1 : 0; a.m = m;
-        a.stage = g->d_stage.p; a.L = stage_layout(n, m);
-        a.node_id = g->node_id.p; a.node_type = g->node_type.p; a.rowptr = g->rowptr.p; a.dst = g->dst.p; a.etype = g->etype.p;
-        a.w_raw = g->w_raw.p; a.w_norm = g->w_norm_raw.p; a.esrc = esrc.p; a.skey = skey.p; a.skey2 = skey2.p; a.sval = sval.p;
-        a.sval2 = sval2.p; a.dangling = g->dangling.p; a.w_src = g->w_src.p; a.flags = flags.p; a.in_ptr = g->in_ptr.p;
-        a.in_src = g->in_src.p; a.in_w = g->in_w.p; a.row_order = g->row_order.p; a.row_order_x = g->row_order_x.p;
-        a.item_rows = g->item_rows.p; a.item_order = g->item_order.p; a.ikey = ikey_s.p; a.ikey2 = ikey2_s.p; a.ival = ival_s.p;
-        a.ival2 = ival2_s.p;
-        a.order_mode = 0;
-        a.top = (uint32_t)m;                                   // (any bound of the in-degrees gives the same order)
-        a.top_bits = bit_length((uint64_t)m) > 0 ? bit_length((uint64_t)m) : 1;
-        a.ptop_bits = a.top_bits > 31 ? 31 : a.top_bits;
-        a.ptop = a.top_bits > 31 ? 0x7FFFFFFFu : a.top;
-        a.n_bits = bit_length((uint64_t)n);
-        a.id_key_top = g->id_key_top; a.id_key_bits = g->id_key_bits;
-        a.pin_out = pin;
-        a.stamps = nullptr;
-#ifdef RWR_EXPERIMENTS
-        DevBuf<unsigned long long> stamps_d;
-        if (bt_on) { RWR_TRY(stamps_d.alloc(8)); a.stamps = stamps_d.p; }
-#endif
-        hipLaunchKernelGGL(k_build_small, dim3(1), dim3(SMALL_SORT_THREADS), 0, s, a);
-        RWR_HIP(hipGetLastError());
-        g->stage_pending = 0;
-        RWR_HIP(hipEventRecord(e1, s));
-        BT("enqueue one-launch build");
-        g->h_in_ptr.resize((size_t)n + 1);
-        g->h_dangling.resize((size_t)n);
-        RWR_HIP(hipStreamSynchronize(s));                      // the ONE synchronisation of an ego-network-sized build
-        const int64_t nnz_s = reinterpret_cast<const int64_t *>(pin)[0];
-        memcpy(h_flags, pin + 8, sizeof(h_flags));
-        memcpy(g->h_in_ptr.data(), pin + 32, sizeof(int64_t) * ((size_t)n + 1));
-        memcpy(g->h_dangling.data(), pin + 32 + 8 * ((size_t)n + 1), (size_t)n);
-        BT("sync (whole build)");
-#ifdef RWR_EXPERIMENTS
-        if (bt_on) {
-            unsigned long long hs[8];
-            RWR_HIP(hipMemcpy(hs, stamps_d.p, sizeof(hs), hipMemcpyDeviceToHost));
-            unsigned long long rp[16];
-            (void)hipMemcpyFromSymbol(rp, HIP_SYMBOL(rp_dbg), sizeof(rp));
-            fprintf(stderr, "[build] row pass of group 0 (us): setup %.1f sweep1 %.1f sweep2 %.1f; started %.1f after stage 1\n", (rp[1] - rp[0]) / 100.0,
-                    (rp[2] - rp[1]) / 100.0, (rp[3] - rp[2]) / 100.0, (rp[0] - hs[1]) / 100.0);
-            fprintf(stderr, "[build] k_build_small stages (us): unpack %.1f rows %.1f linksort %.1f in_ptr+gather %.1f orders %.1f items %.1f out %.1f\n",
-                    (hs[1] - hs[0]) / 100.0, (hs[2] - hs[1]) / 100.0, (hs[3] - hs[2]) / 100.0, (hs[4] - hs[3]) / 100.0, (hs[5] - hs[4]) / 100.0,
-                    (hs[6] - hs[5]) / 100.0, (hs[7] - hs[6]) / 100.0);
-        }
-#endif
-        if (h_flags[1]) {
-            set_error("rwr_graph_create: a link targets a node outside [0, %d)", n);
-            return RWR_E_RANGE;
-        }
-        g->nnz = nnz_s;
-        g->uniform = h_flags[0] ? 0 : 1;
-        g->nonneg = h_flags[3] ? 0 : 1;
-        g->vf = (g->uniform && g->nonneg && vf_env_s) ? 1 : 0;   // (in_w stays: small.hip reads it)
-        return derive_finish(g, h_flags, e0, e1);
-    }
     if (g->stage_pending) {   // (staged upload, general build: unpack the copy by its own kernel)
         const StageLayout L = stage_layout(n, m);
         const int64_t work = (m > (int64_t)n + 1) ? m : (int64_t)n + 1;
@@ -956,6 +1016,150 @@ int32_t ensure_in_w(rwr_graph *g)
                            g->w_src.p, g->in_w.p);
         RWR_HIP(hipGetLastError());
     }
+    return RWR_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A batch of ego-network-sized graphs built with ONE launch (rwr_eval_graphs, multi.hip).  The reference builds one such
+// graph per fold and methodology (Experiment.cs:69-105) and ten of its threads do so at once (Program.cs:11); handled one
+// graph per call that is two synchronisations and a dozen runtime calls per graph, and the threads queue up behind the
+// runtime rather than the GPU.  Here every graph of the batch gets a workgroup of k_build_small_multi: one H2D copy of all
+// staging slots, one launch, one synchronisation.
+//   fits[i] = 0: graph i does not qualify for the one-launch build (the caller builds it the ordinary way); its handle
+//   is left untouched.
+// Pinned host buffers of one rwr_eval_graphs call, grown on demand: slot 0 the graphs' staging slots and read-back areas,
+// the others the small tables the batch kernels take (argument arrays, test sets, results).  Every host<->device copy of a
+// batch goes through pinned memory: an "asynchronous" copy from pageable memory is staged by the runtime under a process-wide
+// lock and waits for the device.  Allocating pinned memory costs milliseconds, so the sets are recycled through a process-wide
+// pool (a call takes one, gives it back at its end); the calling thread reaches its set through a thread-local pointer.
+constexpr int MULTI_SLOTS = 6;
+struct MultiPins {
+    void *pin[MULTI_SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[MULTI_SLOTS] = {0, 0, 0, 0, 0, 0};
+};
+static std::mutex g_pins_mutex;
+static std::vector<MultiPins *> g_pins;          // parked sets (never freed: a handful of MB per concurrent caller)
+static thread_local MultiPins *tl_pins = nullptr;
+void multi_pins_acquire()
+{
+    if (tl_pins) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pins_mutex);
+        if (!g_pins.empty()) { tl_pins = g_pins.back(); g_pins.pop_back(); }
+    }
+    if (!tl_pins) tl_pins = new MultiPins();
+}
+void multi_pins_release()
+{
+    if (!tl_pins) return;
+    std::lock_guard<std::mutex> lk(g_pins_mutex);
+    g_pins.push_back(tl_pins);
+    tl_pins = nullptr;
+}
+int32_t multi_pinned(int slot, size_t bytes, void **out)
+{
+    if (!tl_pins) { set_error("multi_pinned: no pinned set acquired"); return RWR_E_INVALID; }
+    MultiPins &a = *tl_pins;
+    if (a.cap[slot] < bytes) {
+        if (a.pin[slot]) { (void)hipHostFree(a.pin[slot]); a.pin[slot] = nullptr; a.cap[slot] = 0; }
+        const size_t cap = bytes + bytes / 2 + 4096;
+        RWR_HIP(hipHostMalloc(&a.pin[slot], cap, hipHostMallocMapped | hipHostMallocPortable));
+        a.cap[slot] = cap;
+    }
+    *out = a.pin[slot];
+    return RWR_OK;
+}
+
+bool graph_fits_small_build(int32_t n, int64_t m)
+{
+    static const int stage_env = [] { const char *e = RWR_TUNE_ENV("RWR_STAGE"); return e ? atoi(e) : 1; }();
+    static const bool by_degree = [] { const char *e = RWR_TUNE_ENV("RWR_ROW_ORDER"); return !e || atoi(e) == 0; }();
+    return stage_env && by_degree && n > 0 && n <= STAGE_MAX_N && m >= 0 && m <= STAGE_MAX_M;
+}
+
+int32_t graphs_build_multi(rwr_graph **gs, int32_t count, const rwr_graph_desc *descs, hipStream_t s)
+{
+    if (count <= 0) return RWR_OK;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    // arena: [staging slots of all graphs, contiguous][read-back areas]
+    std::vector<size_t> in_off((size_t)count + 1, 0), out_off((size_t)count + 1, 0);
+    for (int32_t i = 0; i < count; ++i) {
+        const int32_t n = descs[i].n_nodes;
+        const int64_t m = descs[i].rowptr[n];
+        in_off[(size_t)i + 1] = in_off[i] + up(stage_layout(n, m).total + 8);
+        out_off[(size_t)i + 1] = out_off[i] + up(32 + 8 * ((size_t)n + 1) + (size_t)n);
+    }
+    const size_t in_bytes = in_off[count], need = in_bytes + out_off[count];
+    void *pin_v = nullptr, *args_v = nullptr;
+    RWR_TRY(multi_pinned(0, need, &pin_v));
+    RWR_TRY(multi_pinned(1, sizeof(BuildSmallArgs) * (size_t)count, &args_v));
+    uint8_t *pin = static_cast<uint8_t *>(pin_v);
+    BuildSmallArgs *h_args = static_cast<BuildSmallArgs *>(args_v);
+    DevBuf<uint8_t> d_in;
+    DevBuf<BuildSmallArgs> d_args;
+    RWR_TRY(d_in.alloc(in_bytes));
+    RWR_TRY(d_args.alloc((size_t)count));
+    std::vector<SmallBuild> builds((size_t)count);
+#ifdef RWR_EXPERIMENTS
+    static const bool mt_on = [] { const char *e = getenv("RWR_X_MULTI_TIMING"); return e && atoi(e) != 0; }();
+    double mt0 = bt_now(), mt1 = 0, mt2 = 0, mt3 = 0, mt4 = 0, mt_up = 0, mt_begin = 0;
+#endif
+    for (int32_t i = 0; i < count; ++i) {
+        rwr_graph *g = gs[i];
+        g->sm_stage = pin + in_off[i];
+        g->sm_out = pin + in_bytes + out_off[i];
+        g->stage_dev_ext = d_in.p + in_off[i];
+        const rwr_graph_desc &D = descs[i];
+#ifdef RWR_EXPERIMENTS
+        const double u0 = bt_now();
+#endif
+        RWR_TRY(graph_build_upload(g, D.node_id, D.node_type, D.rowptr, D.dst, D.etype, D.w));
+        if (!small_build_ok(g)) { set_error("graphs_build_multi: graph %d does not qualify for the one-launch build", i); return RWR_E_INVALID; }
+#ifdef RWR_EXPERIMENTS
+        const double u1 = bt_now();
+        mt_up += u1 - u0;
+#endif
+        RWR_TRY(small_build_begin(g, true, builds[i]));
+#ifdef RWR_EXPERIMENTS
+        mt_begin += bt_now() - u1;
+#endif
+        h_args[i] = builds[i].a;
+    }
+#ifdef RWR_EXPERIMENTS
+    mt1 = bt_now();
+#endif
+    RWR_HIP(hipMemcpyAsync(d_in.p, pin, in_bytes, hipMemcpyHostToDevice, s));
+    RWR_HIP(hipMemcpyAsync(d_args.p, h_args, sizeof(BuildSmallArgs) * (size_t)count, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_build_small_multi, dim3((unsigned)count), dim3(SMALL_SORT_THREADS), 0, s, d_args.p);
+    RWR_HIP(hipGetLastError());
+#ifdef RWR_EXPERIMENTS
+    mt2 = bt_now();
+#endif
+    RWR_HIP(hipStreamSynchronize(s));
+#ifdef RWR_EXPERIMENTS
+    mt3 = bt_now();
+#endif
+    for (int32_t i = 0; i < count; ++i) {
+        rwr_graph *g = gs[i];
+        const int32_t rc = small_build_end(g, builds[i], nullptr, nullptr);
+        g->sm_stage = nullptr;            // (the arena belongs to the thread, not to the handle)
+        g->sm_out = nullptr;
+        g->stage_dev_ext = nullptr;
+        g->staged = 0;                    // an incremental rebuild of this handle, should one follow, takes the general build
+        if (rc != RWR_OK) {
+            char msg[512];
+            snprintf(msg, sizeof(msg), "%s", rwr_last_error());
+            set_error("graph %d of the batch: %s", i, msg);
+            return rc;
+        }
+    }
+#ifdef RWR_EXPERIMENTS
+    mt4 = bt_now();
+    if (mt_on)
+        fprintf(stderr, "[multi build] %d graphs: prep %.0f us (upload %.0f, begin %.0f), enqueue %.0f, wait %.0f, finish %.0f\n", count, mt1 - mt0,
+                mt_up, mt_begin, mt2 - mt1, mt3 - mt2, mt4 - mt3);
+#endif
     return RWR_OK;
 }
 

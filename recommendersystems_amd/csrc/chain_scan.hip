@@ -451,6 +451,9 @@ __global__ __launch_bounds__(64) void k_cs_carry(int32_t n, int nchunks, const u
 //     incoming sum -- is left to the carry's redo                                                               (CS_REDO).
 // The prediction (k_cs_plan) is folded into the block kernel: every workgroup sums the approximate block sums in front of it.
 constexpr int CS_PLAIN = 0, CS_SPLIT = 1, CS_EXACT = 2, CS_REDO = 3;
+#ifdef RWR_EXPERIMENTS
+__device__ int cs_carry_dbg = 0;     // RWR_X_CARRY_DBG=1: the carry prints what it did with its blocks
+#endif
 constexpr int CS_KIND_SHIFT = 12;                       // cs_e cell: predicted exponent | kind << 12
 constexpr int CS_SIDE_WORDS = 8;                        // a[0..3], after.d0, after.d1, exact, (spare)
 typedef double v2d_t __attribute__((ext_vector_type(2)));
@@ -548,6 +551,9 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
     const double post = pre + ap;
     const int epost = (int)(((unsigned long long)__double_as_longlong(post) >> 52) & 0x7ff);
     if (epre == 0 || epost >= 0x7ff || epost > epre + 1) {
+#ifdef RWR_EXPERIMENTS
+        if (cs_carry_dbg && tid == 0) printf("  block %d: redo kind, pre %.17g (e %d) ap %.17g post e %d\n", c, pre, epre, ap, epost);
+#endif
         if (tid == 0) { ek[oidx] = epre | (CS_REDO << CS_KIND_SHIFT); od0[oidx] = 0; od1[oidx] = 0; }
         return;
     }
@@ -670,6 +676,11 @@ __global__ __launch_bounds__(64) void k_cs_carry1(int32_t n, int nchunks, const 
     const size_t base = (size_t)slot * nchunks;
     double s = 0.0;
     unsigned redo = 0;
+#ifdef RWR_EXPERIMENTS
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_redo = 0;
+    unsigned n_split = 0, n_exact = 0, redo_kind[4] = {0, 0, 0, 0};
+#endif
     struct Win {
         double ap;
         int32_t ek;
@@ -755,9 +766,17 @@ __global__ __launch_bounds__(64) void k_cs_carry1(int32_t n, int nchunks, const 
                 }
             }
         }
+#ifdef RWR_EXPERIMENTS
+        if (handled) { if (kL == CS_SPLIT) ++n_split; else ++n_exact; }
+        const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
         if (!handled) {
             s = cs_redo_block<1>(s, n, nchunks, c + L, slot, 0, dangling, X, seeds, c1, in_ptr, in_src, evoff, evterm, lnk);
             ++redo;
+#ifdef RWR_EXPERIMENTS
+            t_redo += __builtin_amdgcn_s_memrealtime() - tr0;
+            ++redo_kind[kL & 3];
+#endif
         }
         done = L + 1;
         if (done >= WAVE || c + done >= nchunks) {        // the window is exhausted
@@ -766,6 +785,12 @@ __global__ __launch_bounds__(64) void k_cs_carry1(int32_t n, int nchunks, const 
             cur = nxt;
         }
     }
+#ifdef RWR_EXPERIMENTS
+    if (cs_carry_dbg && lane == 0)
+        printf("carry1: %d blocks, applied %u split %u exact, redone %u (plain %u split %u exact %u redo %u), total %.2f us, in redo %.2f us\n",
+               nchunks, n_split, n_exact, redo, redo_kind[0], redo_kind[1], redo_kind[2], redo_kind[3],
+               (double)(__builtin_amdgcn_s_memrealtime() - t_begin) * 0.01, (double)t_redo * 0.01);
+#endif
     if (lane == 0) {
         Y[(size_t)slot * (size_t)n + (size_t)sd] = s;
         // value-free path: the seed row's own z for the next step (the SpMV leaves the seed's row alone)
@@ -866,6 +891,15 @@ static int32_t chain_scan_launch(rwr_graph *g, int G, int tg, const double *X, d
     // single seed per tile: link terms gathered from the z matrix when the caller hands it over (evoff = nullptr tells the
     // kernels), the seed row's next z written by the carry
     const bool self = chain_scan_self_contained(G);
+#ifdef RWR_EXPERIMENTS
+    static const int dbg_once = [] {
+        const char *e = getenv("RWR_X_CARRY_DBG");
+        const int v = e ? atoi(e) : 0;
+        if (v) (void)hipMemcpyToSymbol(HIP_SYMBOL(cs_carry_dbg), &v, sizeof(v));
+        return v;
+    }();
+    (void)dbg_once;
+#endif
     const int64_t *evo = (self && zterms) ? nullptr : d_evoff;
     const double *evt = (self && zterms) ? zterms : g->d_evterm.p;
     if (nchunks <= direct_max) {

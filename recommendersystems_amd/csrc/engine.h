@@ -78,6 +78,11 @@ struct rwr_graph {
     rwr::DevBuf<int32_t> sm_tab;      // small.hip: places of the seed row's addends (per call)
     void *sm_pin = nullptr;           // small.hip: pinned host buffer the one-launch kernel writes the ranked list into
     void *sm_stage = nullptr;         // build.hip: pinned staging buffer of an ego-network-sized graph's upload / read-back
+    // a handle built as part of a batch (multi.hip): its staging slot and read-back area lie in the batch's pinned arena, the
+    // device-side landing area in the batch's one buffer (one H2D copy for all graphs); none of them is owned by the handle
+    uint8_t *sm_out = nullptr;
+    const uint8_t *stage_dev_ext = nullptr;
+    int32_t borrowed = 0;             // streams / events / pinned buffers belong to the batch context, not to this handle
     rwr::DevBuf<uint8_t> d_stage;     // ... and its device-side landing area
     int32_t sm_pin_count = -1;        // >= 0: the last single-seed call left its list (that many entries) in sm_pin
     rwr::DevBuf<double> Z0, Z1;       // value-free path: z = ((1-d) x) * w_src of the current / next ranks, same layout
@@ -137,6 +142,16 @@ int32_t graph_build(rwr_graph *g, const int64_t *node_id, const uint8_t *node_ty
 int32_t graph_update_links(rwr_graph *g, int64_t count, const int64_t *idx, const uint8_t *etype, const double *w);
 // value-free graphs: materialise in_w (= w_src[in_src]) for an entry point that runs the weighted kernels
 int32_t ensure_in_w(rwr_graph *g);
+// many ego-network-sized graphs at once (rwr_eval_graphs): one build launch, one call launch, one evaluation launch
+bool graph_fits_small_build(int32_t n, int64_t m);
+void multi_pins_acquire();    // a set of pinned buffers for this thread's rwr_eval_graphs call (from a process-wide pool) ...
+void multi_pins_release();    // ... and back
+int32_t multi_pinned(int slot, size_t bytes, void **out);   // buffer number `slot` (0..5) of the acquired set, at least `bytes` long
+int32_t graphs_build_multi(rwr_graph **gs, int32_t count, const rwr_graph_desc *descs, hipStream_t s);
+int32_t recommend_small_multi(rwr_graph **gs, const int32_t *seeds, int32_t count, double d, int32_t n_iter, hipStream_t s,
+                              rwr::DevBuf<uint8_t> &args_keep);
+int32_t eval_ranked_multi(rwr_graph **gs, int32_t count, const int64_t *test_ptr_host, const int64_t *test_sorted_host,
+                          int64_t *n_hits, double *sum_precision, int64_t *list_len, hipStream_t s);
 
 // runs the power iteration for K seeds and leaves, per seed, the ranked list
 // (mode 0: top-k into host arrays; mode 1: full rank vector of one seed)

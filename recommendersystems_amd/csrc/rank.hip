@@ -8,6 +8,8 @@
 // padding lane) get the largest key and sort to the end.
 #include "engine.h"
 
+#include <cstring>
+
 #include <cstdlib>
 
 namespace rwr {
@@ -576,6 +578,72 @@ int32_t eval_ranked_batch(rwr_graph *g, int32_t K, int64_t row_stride, const int
     RWR_HIP(hipMemcpyAsync(n_hits, d_hits.p, sizeof(int64_t) * (size_t)K, hipMemcpyDeviceToHost, s));
     RWR_HIP(hipMemcpyAsync(sum_precision, d_sum.p, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, s));
     RWR_HIP(hipStreamSynchronize(s));
+    return RWR_OK;
+}
+
+// one block per GRAPH of a batch (rwr_eval_graphs): each graph's own ranked list against its test set
+struct EvalMultiArgs {
+    const int64_t *ranked;
+    const int32_t *count;
+};
+__global__ __launch_bounds__(1024) void k_eval_ranked_multi(const EvalMultiArgs *__restrict__ args,
+                                                            const int64_t *__restrict__ test_sorted,
+                                                            const int64_t *__restrict__ test_ptr, double *__restrict__ terms,
+                                                            int64_t *__restrict__ out_hits, double *__restrict__ out_sum,
+                                                            int32_t *__restrict__ out_len)
+{
+    const int k = blockIdx.x;
+    const EvalMultiArgs a = args[k];
+    const int64_t t0 = test_ptr[k];
+    const int32_t cnt = a.count[0];
+    if (threadIdx.x == 0) out_len[k] = cnt;
+    eval_ranked_body(a.ranked, cnt, test_sorted + t0, (int32_t)(test_ptr[k + 1] - t0), terms + t0, out_hits + k, out_sum + k);
+}
+
+// the lists recommend_small_multi left in the graphs' tables against `count` test sets in CSR form (sorted, de-duplicated)
+int32_t eval_ranked_multi(rwr_graph **gs, int32_t count, const int64_t *test_ptr_host, const int64_t *test_sorted_host,
+                          int64_t *n_hits, double *sum_precision, int64_t *list_len, hipStream_t s)
+{
+    if (count <= 0) return RWR_OK;
+    const int64_t total = test_ptr_host[count];
+    DevBuf<int64_t> d_test, d_ptr, d_hits;
+    DevBuf<double> d_terms, d_sum;
+    DevBuf<int32_t> d_len;
+    DevBuf<EvalMultiArgs> d_args;
+    RWR_TRY(d_test.alloc((size_t)total));
+    RWR_TRY(d_terms.alloc((size_t)total));
+    RWR_TRY(d_ptr.alloc((size_t)count + 1));
+    RWR_TRY(d_hits.alloc((size_t)count));
+    RWR_TRY(d_sum.alloc((size_t)count));
+    RWR_TRY(d_len.alloc((size_t)count));
+    RWR_TRY(d_args.alloc((size_t)count));
+    // every table goes through the thread's pinned buffers (build.hip: multi_pinned): [args][ptr][test ids] in, [hits][sums][len] out
+    const size_t b_args = sizeof(EvalMultiArgs) * (size_t)count, b_ptr = 8 * ((size_t)count + 1), b_test = 8 * (size_t)total;
+    void *in_v = nullptr, *out_v = nullptr;
+    RWR_TRY(multi_pinned(3, b_args + b_ptr + b_test + 64, &in_v));
+    RWR_TRY(multi_pinned(4, (size_t)count * 24 + 64, &out_v));
+    EvalMultiArgs *h = static_cast<EvalMultiArgs *>(in_v);
+    int64_t *h_ptr = reinterpret_cast<int64_t *>(static_cast<uint8_t *>(in_v) + b_args);
+    int64_t *h_test = h_ptr + count + 1;
+    int64_t *o_hits = static_cast<int64_t *>(out_v);
+    double *o_sum = reinterpret_cast<double *>(o_hits + count);
+    int32_t *h_len = reinterpret_cast<int32_t *>(o_sum + count);
+    for (int32_t i = 0; i < count; ++i) { h[i].ranked = gs[i]->d_out_id.p; h[i].count = gs[i]->d_counts.p; }
+    memcpy(h_ptr, test_ptr_host, b_ptr);
+    if (total > 0) memcpy(h_test, test_sorted_host, b_test);
+    if (total > 0) RWR_HIP(hipMemcpyAsync(d_test.p, h_test, b_test, hipMemcpyHostToDevice, s));
+    RWR_HIP(hipMemcpyAsync(d_ptr.p, h_ptr, b_ptr, hipMemcpyHostToDevice, s));
+    RWR_HIP(hipMemcpyAsync(d_args.p, h, b_args, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_eval_ranked_multi, dim3((unsigned)count), dim3(1024), 0, s, d_args.p, d_test.p, d_ptr.p, d_terms.p, d_hits.p,
+                       d_sum.p, d_len.p);
+    RWR_HIP(hipGetLastError());
+    RWR_HIP(hipMemcpyAsync(o_hits, d_hits.p, sizeof(int64_t) * (size_t)count, hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipMemcpyAsync(o_sum, d_sum.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipMemcpyAsync(h_len, d_len.p, sizeof(int32_t) * (size_t)count, hipMemcpyDeviceToHost, s));
+    RWR_HIP(hipStreamSynchronize(s));
+    memcpy(n_hits, o_hits, sizeof(int64_t) * (size_t)count);
+    memcpy(sum_precision, o_sum, sizeof(double) * (size_t)count);
+    if (list_len) for (int32_t i = 0; i < count; ++i) list_len[i] = h_len[i];
     return RWR_OK;
 }
 

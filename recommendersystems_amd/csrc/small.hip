@@ -22,6 +22,7 @@
 #include "pf.h"
 
 #include <climits>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 
@@ -73,7 +74,7 @@ __device__ double sm_fold_scan(double s, const double *M, int base, int cnt, int
     return wave_fold_exact<SM_R>(s, v, lane);
 }
 
-__global__ __launch_bounds__(SM_THREADS) void k_small_rwr(
+__device__ __forceinline__ void small_rwr_body(
     int32_t n, int32_t n_items, int32_t n_long, int32_t seed, double c1, int32_t n_iter, int32_t top_n, int scan_ok,
     const int64_t *__restrict__ in_ptr, const int32_t *__restrict__ in_src, const double *__restrict__ in_w,
     const uint8_t *__restrict__ dangling, const int32_t *__restrict__ row_order, const int64_t *__restrict__ rowptr,
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_rwr(
     const int take = cnt < top_n ? cnt : top_n;
     // the list goes to the device tables (rwr_recommend_eval walks it there) AND straight into pinned host memory, so that
     // the call ends with one stream synchronisation instead of three copies
-    if (tid == 0) { out_count[0] = take; pin_count[0] = take; }
+    if (tid == 0) { out_count[0] = take; if (pin_count) pin_count[0] = take; }
     for (int i = tid; i < take; i += SM_THREADS) {
         const SmCand v = sc[i];
         const int64_t id = (int64_t)(v.lo ^ 0x8000000000000000ull);
@@ -255,9 +256,40 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_rwr(
         __builtin_memcpy(&sv, &u, 8);
         out_id[i] = id;
         out_score[i] = sv;
-        pin_id[i] = id;
-        pin_score[i] = sv;
+        if (pin_id) {                                  // (a batch of graphs keeps its lists on the device: multi.hip)
+            pin_id[i] = id;
+            pin_score[i] = sv;
+        }
     }
+}
+
+__global__ __launch_bounds__(SM_THREADS) void k_small_rwr(
+    int32_t n, int32_t n_items, int32_t n_long, int32_t seed, double c1, int32_t n_iter, int32_t top_n, int scan_ok,
+    const int64_t *__restrict__ in_ptr, const int32_t *__restrict__ in_src, const double *__restrict__ in_w,
+    const uint8_t *__restrict__ dangling, const int32_t *__restrict__ row_order, const int64_t *__restrict__ rowptr,
+    const int32_t *__restrict__ dst, const uint8_t *__restrict__ etype, const int32_t *__restrict__ item_rows,
+    const int64_t *__restrict__ node_id, double *X, double *Y, int32_t *tab, int64_t *__restrict__ out_id,
+    double *__restrict__ out_score, int32_t *__restrict__ out_count, int64_t *__restrict__ pin_id,
+    double *__restrict__ pin_score, int32_t *__restrict__ pin_count)
+{
+    small_rwr_body(n, n_items, n_long, seed, c1, n_iter, top_n, scan_ok, in_ptr, in_src, in_w, dangling, row_order, rowptr, dst, etype,
+                   item_rows, node_id, X, Y, tab, out_id, out_score, out_count, pin_id, pin_score, pin_count);
+}
+
+// one workgroup per graph of a batch (rwr_eval_graphs): the ranked lists stay in each graph's device tables
+struct SmallRwrArgs {
+    int32_t n, n_items, n_long, seed, top_n, pad0;
+    const int64_t *in_ptr; const int32_t *in_src; const double *in_w; const uint8_t *dangling; const int32_t *row_order;
+    const int64_t *rowptr; const int32_t *dst; const uint8_t *etype; const int32_t *item_rows; const int64_t *node_id;
+    double *X, *Y; int32_t *tab; int64_t *out_id; double *out_score; int32_t *out_count;
+};
+__global__ __launch_bounds__(SM_THREADS) void k_small_rwr_multi(const SmallRwrArgs *__restrict__ args, double c1, int32_t n_iter,
+                                                                int scan_ok)
+{
+    const SmallRwrArgs a = args[blockIdx.x];
+    small_rwr_body(a.n, a.n_items, a.n_long, a.seed, c1, n_iter, a.top_n, scan_ok, a.in_ptr, a.in_src, a.in_w, a.dangling, a.row_order,
+                   a.rowptr, a.dst, a.etype, a.item_rows, a.node_id, a.X, a.Y, a.tab, a.out_id, a.out_score, a.out_count, nullptr,
+                   nullptr, nullptr);
 }
 
 // the seed row's addend sequence (one restart addend per node + one addend per link INTO the seed; multi-edges can make
@@ -322,6 +354,60 @@ int32_t recommend_small(rwr_graph *g, int32_t seed, double d, int32_t n_iter, in
     }
     g->sm_pin_count = cnt;
     *count = cnt;
+    return RWR_OK;
+}
+
+
+// One single-seed Recommendation on each of `count` ego-network-sized graphs as ONE launch (every graph must pass
+// small_path_ok / small_path_seed_ok).  Enqueued on `s`; the full ranked lists are left in each graph's d_out_id /
+// d_out_score / d_counts.  args_keep receives the kernel's argument table.
+int32_t recommend_small_multi(rwr_graph **gs, const int32_t *seeds, int32_t count, double d, int32_t n_iter, hipStream_t s,
+                              DevBuf<uint8_t> &args_keep)
+{
+    if (count <= 0) return RWR_OK;
+    constexpr size_t smem = ((size_t)SM_MCAP + SM_MCAP / 64 + 64 + (size_t)SM_WAVES * 2 * WAVE) * sizeof(double) +
+                            (size_t)SM_MAX_N * sizeof(int2);
+    static std::mutex attr_mu;
+    static bool attr_done[64];                   // per device, once per process
+    int dev = 0;
+    RWR_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(attr_mu);
+        if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+            RWR_HIP(hipFuncSetAttribute((const void *)k_small_rwr_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr_done[dev] = true;
+        }
+    }
+    void *h_v = nullptr;
+    RWR_TRY(multi_pinned(2, sizeof(SmallRwrArgs) * (size_t)count, &h_v));      // (pinned: see build.hip, multi_pinned)
+    SmallRwrArgs *h = static_cast<SmallRwrArgs *>(h_v);
+    for (int32_t i = 0; i < count; ++i) {
+        rwr_graph *g = gs[i];
+        RWR_TRY(ensure_in_w(g));
+        RWR_TRY(g->X.ensure((size_t)g->n));
+        RWR_TRY(g->Y.ensure((size_t)g->n));
+        RWR_TRY(g->d_out_id.ensure((size_t)SM_MAX_ITEMS + 64));
+        RWR_TRY(g->d_out_score.ensure((size_t)SM_MAX_ITEMS + 64));
+        RWR_TRY(g->d_counts.ensure(64));
+        RWR_TRY(g->sm_tab.ensure((size_t)SM_MCAP));
+        SmallRwrArgs &a = h[i];
+        a.n = g->n; a.n_items = g->n_items; a.n_long = g->bin_end[0]; a.seed = seeds[i]; a.top_n = g->n_items; a.pad0 = 0;
+        a.in_ptr = g->in_ptr.p; a.in_src = g->in_src.p; a.in_w = g->in_w.p; a.dangling = g->dangling.p; a.row_order = g->row_order.p;
+        a.rowptr = g->rowptr.p; a.dst = g->dst.p; a.etype = g->etype.p; a.item_rows = g->item_rows.p; a.node_id = g->node_id.p;
+        a.X = g->X.p; a.Y = g->Y.p; a.tab = g->sm_tab.p; a.out_id = g->d_out_id.p; a.out_score = g->d_out_score.p;
+        a.out_count = g->d_counts.p;
+        g->sm_pin_count = -1;
+        g->stats.seeds_done += 1;
+    }
+    RWR_TRY(args_keep.alloc(sizeof(SmallRwrArgs) * (size_t)count));
+    SmallRwrArgs *d_args_p = reinterpret_cast<SmallRwrArgs *>(args_keep.p);
+    RWR_HIP(hipMemcpyAsync(d_args_p, h, sizeof(SmallRwrArgs) * (size_t)count, hipMemcpyHostToDevice, s));
+    const double c1 = 1 - d;                                       // Model.cs:84
+    const int scan_ok = (c1 >= 0.0 && c1 <= 1.0) ? 1 : 0;
+    hipLaunchKernelGGL(k_small_rwr_multi, dim3((unsigned)count), dim3(SM_THREADS), smem, s, d_args_p, c1, n_iter, scan_ok);
+    RWR_HIP(hipGetLastError());
+    // (no synchronisation: the evaluation kernel follows on the same stream; the caller keeps args_keep until that stream has
+    //  been synchronised -- the device-memory cache is shared by all threads)
     return RWR_OK;
 }
 

@@ -221,6 +221,34 @@ class Graph:
             pass
 
 
+def EvaluateGraphs(graphs, seeds, dampingFactor: float, nIteration: int, testSets, *, device: int = -1):
+    """The loop body of the reference's harness (Experiment.cs:69-134) for MANY graphs at once (rwr_eval_graphs):
+    graphs[k].buildGraph(); Recommender(graphs[k]).RecommendationEval(seeds[k], d, T, testSets[k]) for every k, with one
+    build launch, one iteration launch and one evaluation launch for all ego-network-sized graphs of the batch.  The Graph
+    objects are NOT built by this call (no device handle is left behind).  Returns (nHits[K], sumPrecision[K], listLen[K])."""
+    K = len(graphs)
+    if len(seeds) != K or len(testSets) != K:
+        raise ValueError("one seed and one test set per graph")
+    flats = [g._flat if g._flat is not None else g._flatten() for g in graphs]
+    descs = (_lib.rwr_graph_desc * max(K, 1))()
+    for k, (node_id, node_type, rowptr, dst, etype, w) in enumerate(flats):
+        descs[k] = _lib.rwr_graph_desc(int(node_id.shape[0]), 0, _p(node_id, C.c_int64), _p(node_type, C.c_uint8),
+                                       _p(rowptr, C.c_int64), _p(dst, C.c_int32), _p(etype, C.c_uint8), _p(w, C.c_double))
+    seeds_a = np.ascontiguousarray(seeds, dtype=np.int32)
+    ptr = np.zeros(K + 1, dtype=np.int64)
+    for k, t in enumerate(testSets):
+        ptr[k + 1] = ptr[k] + len(t)
+    ids = np.ascontiguousarray([x for t in testSets for x in t], dtype=np.int64) if ptr[K] else np.zeros(1, dtype=np.int64)
+    hits = np.zeros(K, dtype=np.int64)
+    sp = np.zeros(K, dtype=np.float64)
+    ln = np.zeros(K, dtype=np.int64)
+    opts = _lib.rwr_opts(C.sizeof(_lib.rwr_opts), device, -1, 0, 0, 0, 0, 0, 0)
+    _lib.check(_lib.load().rwr_eval_graphs(K, descs, _p(seeds_a, C.c_int32), C.c_float(dampingFactor), int(nIteration),
+                                           _p(ptr, C.c_int64), _p(ids, C.c_int64), C.byref(opts), _p(hits, C.c_int64),
+                                           _p(sp, C.c_double), _p(ln, C.c_int64)))
+    return hits, sp, ln
+
+
 class Model:
     """class Model (Model.cs:5-116) backed by rwr_model_run."""
 

@@ -369,6 +369,74 @@ def test_recommend_eval_batch_bitwise(amd):
         rec.RecommendationEvalBatch(np.array([0, 99999], dtype=np.int32), 0.15, 8, [[], []])
 
 
+def test_eval_graphs_batch_bitwise(amd):
+    """rwr_eval_graphs: many graphs, one seed and one test set each -- entry k equals create + RecommendationEval + destroy
+    on graph k and the oracle's evaluation of the oracle's list.  The batch mixes graphs of the one-launch paths (most),
+    weighted and relabelled (UNDEFINED) links, a dangling seed, an empty test set, a graph without items, a graph beyond the
+    one-launch call's item limit and one beyond the one-launch build's node limit (both take the single-graph path inside)."""
+    from oracle.c_oracle import evaluate as c_eval
+    rng = np.random.default_rng(11)
+    graphs, seeds, tests = [], [], []
+    for k in range(14):
+        g = gg.random_graph(100 + k, n_users=int(rng.integers(20, 400)), n_items=int(rng.integers(30, 2500)),
+                            n_likes=int(rng.integers(200, 9000)), n_friend=int(rng.integers(0, 300)),
+                            n_mention=int(rng.integers(0, 200)), n_author=int(rng.integers(0, 100)),
+                            p_undefined=0.15 if k % 3 == 0 else 0.0, uniform=(k % 4 == 1))
+        graphs.append(g)
+        seeds.append(int(rng.integers(0, 20)))
+    # a dangling seed: every out-link of user 3 of graph 2 relabelled UNDEFINED
+    et = graphs[2]["etype"].copy()
+    et[graphs[2]["rowptr"][3]:graphs[2]["rowptr"][4]] = gg.EDGE_UNDEFINED
+    graphs[2] = dict(graphs[2], etype=et)
+    seeds[2] = 3
+    # beyond the one-launch call (items > 4096) and beyond the one-launch build (nodes > 8192)
+    graphs.append(gg.random_graph(300, n_users=200, n_items=5000, n_likes=12000))
+    seeds.append(5)
+    graphs.append(gg.random_graph(301, n_users=1500, n_items=9000, n_likes=30000))
+    seeds.append(9)
+    # no ITEM node at all
+    gi = gg.random_graph(302, n_users=50, n_items=40, n_likes=300)
+    gi = dict(gi, node_type=np.where(gi["node_type"] == gg.NODE_ITEM, gg.NODE_USER, gi["node_type"]).astype(np.uint8))
+    graphs.append(gi)
+    seeds.append(1)
+    for k, g in enumerate(graphs):
+        item_ids = g["node_id"][g["node_type"] == gg.NODE_ITEM]
+        t = rng.choice(item_ids, min(len(item_ids), int(rng.integers(0, 50))), replace=False).tolist() if len(item_ids) else []
+        if k == 1:
+            t = []
+        if k == 4:
+            t = t + t[:3] + [-5, 10 ** 14]
+        tests.append(t)
+    Gs = [amd.Graph.from_flat(**{k: g[k] for k in ("node_id", "node_type", "rowptr", "dst", "etype", "w")}) for g in graphs]
+    hits, sp, ln = amd.EvaluateGraphs(Gs, seeds, 0.15, 7, tests)
+    for k, g in enumerate(graphs):
+        F = FlatGraph(**g)
+        ids, _ = F.recommend(int(seeds[k]), 0.15, 7)
+        oh, osp = c_eval(ids, sorted(set(tests[k])))
+        assert ln[k] == len(ids) and hits[k] == oh, k
+        assert np.float64(sp[k]).view(np.uint64) == np.float64(osp).view(np.uint64), k
+        G1 = dev_graph(amd, g)
+        one = amd.Recommender(G1).RecommendationEval(int(seeds[k]), 0.15, 7, set(tests[k]))
+        assert one == (int(hits[k]), float(sp[k]), int(ln[k])), k
+        G1.close()
+    # twice the same batch (the thread's pinned arena and the handle pool are reused), and an empty one
+    h2, s2, l2 = amd.EvaluateGraphs(Gs, seeds, 0.15, 7, tests)
+    assert (h2 == hits).all() and (s2.view(np.uint64) == sp.view(np.uint64)).all() and (l2 == ln).all()
+    h0, s0, l0 = amd.EvaluateGraphs([], [], 0.15, 7, [])
+    assert len(h0) == 0
+    # errors name the graph: a seed out of range, a link target out of range
+    with pytest.raises(Exception, match="graph 1"):
+        amd.EvaluateGraphs(Gs[:2], [0, 10 ** 6], 0.15, 7, tests[:2])
+    bad = dict(graphs[0], dst=graphs[0]["dst"].copy())
+    bad["dst"][0] = 10 ** 6
+    Gb = amd.Graph.from_flat(**{k: bad[k] for k in ("node_id", "node_type", "rowptr", "dst", "etype", "w")})
+    with pytest.raises(Exception, match="graph 1"):
+        amd.EvaluateGraphs([Gs[0], Gb], seeds[:2], 0.15, 7, tests[:2])
+    # ... and the library is usable afterwards
+    h3, _, _ = amd.EvaluateGraphs(Gs[:3], seeds[:3], 0.15, 7, tests[:3])
+    assert (h3 == hits[:3]).all()
+
+
 def test_cpp_host_mirror_runs_the_kats():
     """include/recommenders/rwr_based.hpp + tests/cpp/experiment_like.cpp: the caller pattern of
     Experiment.cs:104-128 in C++ against librwr (built by __graft_entry__.build())."""
