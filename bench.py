@@ -384,6 +384,22 @@ def bench_c1(args):
                                   "results_identical_to_batched": res_single == res},
            "roofline": None, "roofline_note": "latency-bound by design: every graph is one workgroup of the build kernel and one "
                                               "of the iteration kernel; see DESIGN.md 3.6"}
+    # the same entry point from NATIVE host threads (the reference's host is compiled code: Program.cs:11): Python threads
+    # serialise on the interpreter between calls, so the rate above understates what a C# / C++ host gets.  Built and run as a
+    # child process (tools/eval_graphs_threads.cpp, its own synthetic graphs of the same size range); absent g++ = skipped.
+    try:
+        exe = os.path.join(tmp, "egt")
+        pkg = os.path.join(ROOT, "recommendersystems_amd")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tools", "eval_graphs_threads.cpp"), "-o", exe, os.path.join(pkg, "librwr.so"),
+                               "-Wl,-rpath," + pkg], stderr=subprocess.DEVNULL)
+        per = (len(graphs) + args.host_threads - 1) // args.host_threads
+        txt = subprocess.run([exe, str(per), "30"], capture_output=True, text=True, timeout=120).stdout
+        out["native_host_threads"] = {"note": f"tools/eval_graphs_threads.cpp: T std::threads x {per} graphs per rwr_eval_graphs call x 30 calls "
+                                              "(600..2100-item synthetic graphs built in C++), graphs/s",
+                                      "by_threads": [json.loads(l) for l in txt.splitlines() if l.startswith("{")]}
+    except Exception as e:                                   # noqa: BLE001
+        out["native_host_threads"] = {"skipped": repr(e)[:200]}
     if not args.no_cpu_baseline:
         from oracle.c_oracle import FlatGraph, evaluate
         cres = [None] * len(graphs)

@@ -59,6 +59,23 @@ namespace Recommenders.RWRBased {
             if (GraphFieldLimit > 0 && m <= GraphFieldLimit) LoadNormalizedGraph();
         }
 
+        // the flat arrays buildGraph() hands to librwr, without building: Recommender.EvaluateGraphs sends many graphs at once
+        internal void Flatten(out long[] id, out byte[] type, out long[] rp, out int[] d, out byte[] et, out double[] w) {
+            int n = nodes.Count;
+            id = new long[n]; type = new byte[n]; rp = new long[n + 1];
+            for (int i = 0; i < n; i++) {
+                id[i] = nodes[i].id; type[i] = (byte)nodes[i].type;
+                rp[i + 1] = rp[i] + (edges.ContainsKey(i) ? edges[i].Count : 0);
+            }
+            long m = rp[n];
+            d = new int[m]; et = new byte[m]; w = new double[m];
+            long e = 0;
+            for (int i = 0; i < n; i++) {
+                if (!edges.ContainsKey(i)) continue;
+                foreach (ForwardLink l in edges[i]) { d[e] = l.targetNode; et[e] = (byte)l.type; w[e] = l.weight; e++; }
+            }
+        }
+
         bool SameTopology(long[] id, byte[] type, long[] oldRowptr, int[] oldDst) {
             if (oldRowptr == null || oldRowptr.Length != rowptr.Length || oldDst.Length != dst.Length) return false;
             for (int i = 0; i < rowptr.Length; i++) if (oldRowptr[i] != rowptr[i]) return false;

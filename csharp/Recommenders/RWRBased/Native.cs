@@ -12,6 +12,13 @@ namespace Recommenders.RWRBased {
         public int seed_row_kernel, reserved0;
     }
 
+    // one graph of a rwr_eval_graphs batch: pointers to the caller's (pinned) arrays -- include/rwr.h: rwr_graph_desc
+    [StructLayout(LayoutKind.Sequential)]
+    internal struct RwrGraphDesc {
+        public int n_nodes, reserved0;
+        public IntPtr node_id, node_type, rowptr, dst, etype, w;
+    }
+
     internal sealed class GraphHandle : SafeHandle {
         // the reference types have no Dispose(): native memory is released by the finalizer of this SafeHandle
         public GraphHandle() : base(IntPtr.Zero, true) { }
@@ -39,6 +46,10 @@ namespace Recommenders.RWRBased {
             long n_test, out long n_hits, out double sum_precision, out long list_len);
         [DllImport(Lib)] public static extern int rwr_recommend_eval_batch(GraphHandle g, int[] seeds, int K, float d, int n_iter,
             long[] test_ptr, long[] test_ids, long[] n_hits, double[] sum_precision, long[] list_len);
+        // many ego-network-sized graphs at once: build + Recommendation(seed) + hits / sum of precisions per graph, a constant
+        // number of launches for the whole batch (Recommender.EvaluateGraphs)
+        [DllImport(Lib)] public static extern int rwr_eval_graphs(int count, RwrGraphDesc[] graphs, int[] seeds, float d, int n_iter,
+            long[] test_ptr, long[] test_ids, ref RwrOpts opts, long[] n_hits, double[] sum_precision, long[] list_len);
         [DllImport(Lib)] public static extern int rwr_model_run(GraphHandle g, int seed, double d, int run_mode, double value,
             double[] rank_out, out long iters_out);
 

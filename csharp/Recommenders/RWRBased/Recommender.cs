@@ -25,6 +25,39 @@ namespace Recommenders.RWRBased {
             return result;
         }
 
+        // addition: the harness's loop body (Experiment.cs:69-134) for MANY graphs in one call -- graphs[k].buildGraph(),
+        // Recommendation(seeds[k], d, nIteration) and the hits / sum-of-precisions walk over testSets[k] -- without building the
+        // Graph objects one by one.  hits[k] and sumPrecision[k] are exactly what the loop computes for graph k.
+        public static void EvaluateGraphs(Graph[] graphs, int[] seeds, float dampingFactor, int nIteration, HashSet<long>[] testSets,
+                                          out long[] hits, out double[] sumPrecision) {
+            int K = graphs.Length;
+            var descs = new RwrGraphDesc[K];
+            var pins = new List<System.Runtime.InteropServices.GCHandle>();
+            System.Func<object, System.IntPtr> pin = a => {
+                var h = System.Runtime.InteropServices.GCHandle.Alloc(a, System.Runtime.InteropServices.GCHandleType.Pinned);
+                pins.Add(h);
+                return h.AddrOfPinnedObject();
+            };
+            var testPtr = new long[K + 1];
+            var testIds = new List<long>();
+            try {
+                for (int k = 0; k < K; k++) {
+                    long[] nodeId; byte[] nodeType; long[] rowptr; int[] dst; byte[] etype; double[] w;
+                    graphs[k].Flatten(out nodeId, out nodeType, out rowptr, out dst, out etype, out w);
+                    descs[k] = new RwrGraphDesc { n_nodes = nodeId.Length, reserved0 = 0, node_id = pin(nodeId), node_type = pin(nodeType),
+                                                  rowptr = pin(rowptr), dst = pin(dst), etype = pin(etype), w = pin(w) };
+                    testIds.AddRange(testSets[k]);
+                    testPtr[k + 1] = testIds.Count;
+                }
+                hits = new long[K]; sumPrecision = new double[K];
+                var opts = new RwrOpts { struct_size = System.Runtime.InteropServices.Marshal.SizeOf(typeof(RwrOpts)), device = -1, mode = -1 };
+                Native.Check(Native.rwr_eval_graphs(K, descs, seeds, dampingFactor, nIteration, testPtr, testIds.ToArray(), ref opts, hits,
+                                                    sumPrecision, null));
+            } finally {
+                foreach (var h in pins) h.Free();
+            }
+        }
+
         // addition: many seeds in one call (results identical to calling Recommendation per seed)
         public List<KeyValuePair<long, double>>[] RecommendationBatch(int[] seeds, float dampingFactor, int nIteration, int topN) {
             if (topN < 1) throw new System.ArgumentOutOfRangeException("topN", "RecommendationBatch needs topN >= 1 (rwr_recommend_batch)");

@@ -33,6 +33,17 @@ def test_struct_layouts_match_header():
     # the first 32 bytes are the layout the C# shim passes (struct_size = 32); later fields are appended
     assert C.sizeof(L.rwr_opts) == 40 and L.rwr_opts.workspace_bytes.offset == 24 and L.rwr_opts.seed_row_kernel.offset == 32
     assert L.rwr_stats.nnz_raw.offset == 8 and L.rwr_stats.build_ms.offset == 40
+    # rwr_graph_desc (rwr_eval_graphs): two int32, then six pointers -- the header's field order, the ctypes mirror's and the
+    # C# shim's ([StructLayout(Sequential)] RwrGraphDesc: int, int, IntPtr x 6)
+    hdr = open(os.path.join(ROOT, "include", "rwr.h")).read()
+    body = re.search(r"typedef struct rwr_graph_desc\s*\{(.*?)\}\s*rwr_graph_desc;", hdr, re.S).group(1)
+    names = re.findall(r"\b(\w+)\s*;", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert names == [f for f, _ in L.rwr_graph_desc._fields_]
+    assert C.sizeof(L.rwr_graph_desc) == 56 and L.rwr_graph_desc.node_id.offset == 8 and L.rwr_graph_desc.w.offset == 48
+    cs = open(os.path.join(ROOT, "csharp", "Recommenders", "RWRBased", "Native.cs")).read()
+    cs_body = re.search(r"struct RwrGraphDesc\s*\{(.*?)\}", cs, re.S).group(1)
+    cs_names = [x.strip() for _, group in re.findall(r"public\s+(int|IntPtr)\s+([^;]+);", cs_body) for x in group.split(",")]
+    assert cs_names == names
 
 
 def test_argument_validation_without_gpu():
@@ -57,6 +68,19 @@ def test_argument_validation_without_gpu():
     assert lib.rwr_graph_destroy(None) == L.RWR_OK
     assert lib.rwr_graph_update_links(None, 0, None, None, None) == L.RWR_E_INVALID
     assert b"graph is NULL" in lib.rwr_last_error()
+    # rwr_eval_graphs: an empty batch is fine, a graph without nodes is named
+    assert lib.rwr_eval_graphs(0, None, None, C.c_float(0.15), 3, None, None, None, None, None, None) == L.RWR_OK
+    d = (L.rwr_graph_desc * 2)()
+    rp0 = np.array([0, 0, 0], dtype=np.int64)
+    d[0] = L.rwr_graph_desc(2, 0, p(node_id, C.c_int64), p(node_type, C.c_uint8), p(rp0, C.c_int64), None, None, None)
+    d[1] = L.rwr_graph_desc(0, 0, None, None, None, None, None, None)
+    seeds = np.zeros(2, dtype=np.int32)
+    tp = np.zeros(3, dtype=np.int64)
+    hits = np.zeros(2, dtype=np.int64)
+    sp = np.zeros(2, dtype=np.float64)
+    assert lib.rwr_eval_graphs(2, d, p(seeds, C.c_int32), C.c_float(0.15), 3, p(tp, C.c_int64), None, None, p(hits, C.c_int64),
+                               p(sp, C.c_double), None) == L.RWR_E_INVALID
+    assert b"graph 1" in lib.rwr_last_error()
 
 
 def test_product_package_never_touches_the_oracle():

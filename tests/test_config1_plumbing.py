@@ -56,3 +56,12 @@ def test_result_dat_identical_on_gpu_and_oracle(db):
     for (m, f, a), (_, _, b) in zip(o_lists, g_lists):
         assert [x[0] for x in a] == [x[0] for x in b], (m, f)
         assert [x[1].hex() for x in a] == [float(x[1]).hex() for x in b], (m, f)
+
+
+@pytest.mark.gpu
+def test_result_dat_identical_through_the_batch_entry_point(db):
+    """All 48 graphs of the ego network (16 methodologies x 3 folds) handed to ONE rwr_eval_graphs call: the same result.dat."""
+    import recommendersystems_amd as amd
+    o_lines, _ = th.run_k_fold(th.oracle_api(), db, 1000, METHODS, 3, 10)
+    g_lines = th.run_k_fold_batched(th.gpu_api(), db, 1000, METHODS, 3, 10, amd.EvaluateGraphs)
+    assert g_lines == o_lines

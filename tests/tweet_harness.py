@@ -291,3 +291,38 @@ def run_k_fold(api: Api, db_path: str, ego: int, methodologies, nFolds: int, nIt
                 graph.close()
         lines.append(f"{ego}\t{methodology}\t{nFolds}\t{nIterations}\t{int(hits_total)}\t{cntLikes}\t{repr(ap_total / nFolds)}")   # :144-153
     return lines, lists
+
+
+def run_k_fold_batched(api: Api, db_path: str, ego: int, methodologies, nFolds: int, nIterations: int, evaluate_graphs):
+    """The same experiment with the loop turned inside out for a batch entry point: every (methodology, fold) graph is
+    configured first (Experiment.cs:69-105, relabels included), then ONE call evaluates them all --
+    evaluate_graphs(graphs, seeds, d, T, testSets) -> (nHits[], sumPrecision[], listLen[]) -- and the result.dat lines are
+    assembled as Experiment.cs:131-153 does.  Returns the lines."""
+    graphs, tests, keys = [], [], []
+    cntLikes = 0
+    for methodology in methodologies:
+        for fold in range(nFolds):
+            loader = DataLoader(api, db_path, ego, nFolds)
+            if fold == 0:
+                if not loader.checkEgoNetworkValidation():
+                    return []
+                cntLikes = loader.cntLikesOfEgoUser
+            loader.graphConfiguration(methodology, fold)
+            if methodology in RELABEL:
+                for forwardLinks in loader.allLinks.values():
+                    for l in forwardLinks:
+                        if l.type == api.FRIENDSHIP:
+                            l.type = api.UNDEFINED
+            graphs.append(api.Graph(loader.allNodes, loader.allLinks))
+            tests.append(set(loader.testSet))
+            keys.append(methodology)
+    hits, sp, _ = evaluate_graphs(graphs, [0] * len(graphs), 0.15, nIterations, tests)
+    lines = []
+    for methodology in methodologies:
+        hits_total, ap_total = 0.0, 0.0
+        for q, m in enumerate(keys):
+            if m == methodology:
+                hits_total += int(hits[q])
+                ap_total += 0 if int(hits[q]) == 0 else float(sp[q]) / int(hits[q])
+        lines.append(f"{ego}\t{methodology}\t{nFolds}\t{nIterations}\t{int(hits_total)}\t{cntLikes}\t{repr(ap_total / nFolds)}")
+    return lines
