@@ -803,6 +803,8 @@ static int32_t graph_derive(rwr_graph *g, bool first)
     g->sw_meta.release();
     g->sw_order.release();
     g->sw_ent.release();
+    g->sw_wgblk.release();
+    g->sw_partial = 0;
     g->part_G = 0;   // a row-partitioned run sized for the previous matrix is over: rwr_part_step asks for a new rwr_part_begin
 
     const int32_t n = g->n;

@@ -68,6 +68,9 @@ struct rwr_graph {
     // single-seed SpMV of value-free graphs as a source-block sweep with z staged through LDS (sweep.hip): 0 = not decided
     // yet, 1 = tables built, -1 = this graph does not qualify; re-decided after every (re)build
     int32_t sw_state = 0, sw_B = 0, sw_BN = 0, sw_K = 0, sw_nwg = 0, sw_wpg = 0, sw_hub0 = 0;
+    int32_t sw_rows = 0;              // rows the sweep serves (all non-hub rows, or -- sw_partial -- the non-hub ITEM rows only)
+    int32_t sw_partial = 0;           // 1: phase 0 (ITEM rows) by the sweep, phase 1 by the row-binned kernel beside it
+    rwr::DevBuf<uint32_t> sw_wgblk;   // [workgroup][block]: does any row of the workgroup read that block (else its refill is skipped)
     int64_t sw_words = 0;             // 64-bit words of the entry stream (4 block-local 16-bit indices each)
     rwr::DevBuf<int32_t> sw_order;    // rows in sweep order (row_order_x without its hub rows)
     rwr::DevBuf<uint4> sw_meta;       // [wave][block]: first word-row of the chunk, piece lengths of the wave's slots

@@ -394,7 +394,7 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
         // beside the sweep kernel: ask for 36 KB of (unused) LDS per workgroup, more than a CU has left beside a sweep
         // workgroup (160 - 128 KB), so that the hub rows run on the CUs the sweep leaves free (sweep.hip: RWR_SWEEP_WGS)
         static const int hub_lds_env = [] { const char *e = RWR_TUNE_ENV("RWR_HUB_LDS"); return e ? atoi(e) : 36864; }();
-        const size_t hub_lds = sweep ? (size_t)hub_lds_env : 0;
+        const size_t hub_lds = (sweep && !g->sw_partial) ? (size_t)hub_lds_env : 0;   // (partial: the sweep holds every CU)
         if (vf)
             hipLaunchKernelGGL(k_spmv_exact_hub<true>, dim3(grid), dim3(WAVE), hub_lds, g->stream3, ra, ra + nh, g->in_ptr.p, g->in_src.p,
                                g->in_w.p, order, gs, Y, seeds, c1, skip, g->w_src.p, zout, prefix, act, nz_out);
@@ -403,7 +403,8 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
                                g->in_w.p, order, gs, Y, seeds, c1, skip, g->w_src.p, zout, prefix, act, nz_out);
     };
     auto blocks_for = [](int64_t rows, int W) { const int64_t b = (rows * W + 255) / 256; return (int)(b < 0 ? 0 : (b > 16384 ? 16384 : b)); };
-    auto launch = [&](const int32_t *order, int32_t ra0, int32_t rows, const int32_t bins[3], int32_t nh) {
+    // (sb: the stream of the row-binned kernel -- the main stream, or stream3 when the sweep holds the main stream)
+    auto launch = [&](const int32_t *order, int32_t ra0, int32_t rows, const int32_t bins[3], int32_t nh, hipStream_t sb) {
         if (rows <= 0) return;
         if (!hubs) nh = 0;
         launch_hubs(order, ra0, nh);
@@ -418,32 +419,39 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
         const int nb0 = blocks_for(b0 - ra, 64), nb1 = blocks_for(b1 - b0, 16), nb2 = blocks_for(b2 - b1, 4), nb3 = blocks_for(rend - b2, 1);
         if (nb0 + nb1 + nb2 + nb3 <= 0) return;
         if (vf)
-            hipLaunchKernelGGL(k_spmv_exact_binned<true>, dim3((unsigned)(nb0 + nb1 + nb2 + nb3)), dim3(256), 0, s, nb0, nb1, nb2, nb3, ra, b0,
+            hipLaunchKernelGGL(k_spmv_exact_binned<true>, dim3((unsigned)(nb0 + nb1 + nb2 + nb3)), dim3(256), 0, sb, nb0, nb1, nb2, nb3, ra, b0,
                                b1, b2, rend, g->in_ptr.p, g->in_src.p, g->in_w.p, order, gs, Y, seeds, c1, skip, act, nz_out, g->w_src.p, zout);
         else
-            hipLaunchKernelGGL(k_spmv_exact_binned<false>, dim3((unsigned)(nb0 + nb1 + nb2 + nb3)), dim3(256), 0, s, nb0, nb1, nb2, nb3, ra, b0,
+            hipLaunchKernelGGL(k_spmv_exact_binned<false>, dim3((unsigned)(nb0 + nb1 + nb2 + nb3)), dim3(256), 0, sb, nb0, nb1, nb2, nb3, ra, b0,
                                b1, b2, rend, g->in_ptr.p, g->in_src.p, g->in_w.p, order, gs, Y, seeds, c1, skip, act, nz_out, g->w_src.p, zout);
     };
     if (sweep) {
 #ifdef RWR_EXPERIMENTS
         // timing probes of the experiments build only (results are WRONG with either set): one of the two kernels alone
         static const int x_only = [] { const char *e = getenv("RWR_X_SWEEP_ONLY"); return e ? atoi(e) : 0; }();
-        if (x_only != 1 && g->x_hub[0] + g->x_hub[1] > 0) fork();
+        if (x_only != 1 && (g->x_hub[0] + g->x_hub[1] > 0 || g->sw_partial)) fork();
         if (x_only != 2) launch_sweep(g, zin, Y, zout, seeds, skip, c1, s);
-        if (x_only != 1) { launch_hubs(g->row_order_x.p, 0, g->x_hub[0]); launch_hubs(g->row_order_x.p, g->x_rows[0], g->x_hub[1]); }
+        if (x_only != 1) {
+            launch_hubs(g->row_order_x.p, 0, g->x_hub[0]);
+            if (g->sw_partial) launch(g->row_order_x.p, g->x_rows[0], g->x_rows[1], g->x_bins[1], g->x_hub[1], g->stream3);
+            else launch_hubs(g->row_order_x.p, g->x_rows[0], g->x_hub[1]);
+        }
 #else
         // (the sweep first: its one workgroup per CU needs 128 KB of LDS and 16 wave slots at once, which a CU already full
         //  of hub-row waves could not offer until they retire; the hub kernel then fills what is left beside it)
-        if (g->x_hub[0] + g->x_hub[1] > 0) fork();          // (the fork point lies BEFORE the sweep in the main stream)
+        if (g->x_hub[0] + g->x_hub[1] > 0 || g->sw_partial) fork();   // (the fork point lies BEFORE the sweep in the main stream)
         launch_sweep(g, zin, Y, zout, seeds, skip, c1, s);
         launch_hubs(g->row_order_x.p, 0, g->x_hub[0]);
-        launch_hubs(g->row_order_x.p, g->x_rows[0], g->x_hub[1]);
+        // the sweep serves the ITEM rows only (sweep.hip: more rows than its waves have accumulators for): the other rows by the
+        // row-binned kernel beside it
+        if (g->sw_partial) launch(g->row_order_x.p, g->x_rows[0], g->x_rows[1], g->x_bins[1], g->x_hub[1], g->stream3);
+        else launch_hubs(g->row_order_x.p, g->x_rows[0], g->x_hub[1]);
 #endif
     } else if (by_degree && phases) {
-        launch(g->row_order_x.p, 0, g->x_rows[0], g->x_bins[0], g->x_hub[0]);
-        launch(g->row_order_x.p, g->x_rows[0], g->x_rows[1], g->x_bins[1], g->x_hub[1]);
+        launch(g->row_order_x.p, 0, g->x_rows[0], g->x_bins[0], g->x_hub[0], s);
+        launch(g->row_order_x.p, g->x_rows[0], g->x_rows[1], g->x_bins[1], g->x_hub[1], s);
     } else {
-        launch(g->row_order.p, 0, g->n, g->bin_end, g->bin_hub);
+        launch(g->row_order.p, 0, g->n, g->bin_end, g->bin_hub, s);
     }
     if (forked) {                                       // the step is complete when both kernels are
         (void)hipEventRecord(g->ev_h1, g->stream3);

@@ -20,6 +20,7 @@
 #include "engine.h"
 
 #include <cstdlib>
+#include <vector>
 
 namespace rwr {
 
@@ -107,6 +108,27 @@ __global__ __launch_bounds__(256) void k_sw_meta(int nw, int nwg, int wpg, int K
     }
     meta[q] = make_uint4(base[gw] + woff[q], c[0] | (c[1] << 16), c[2] | (c[3] << 16), tot[gw]);
 }
+// per workgroup: the blocks (ascending) in which any of its rows holds an entry -- wgblk[wg * (B + 1)] = their number, the ids
+// behind it.  A workgroup visits only those: the refill, both barriers and the block record of every other block are skipped
+// (on a bipartite graph the ITEM rows read the users' blocks only: 7 of 37 on the 0.6 M-node graph)
+__global__ __launch_bounds__(64) void k_sw_wglist(int nwg, int wpg, int K, int32_t ns, int B, const uint32_t *__restrict__ scnt,
+                                                  uint32_t *__restrict__ wgblk)
+{
+    const int wg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wg >= nwg) return;
+    uint32_t *out = wgblk + (size_t)wg * (B + 1);
+    uint32_t cnt = 0;
+    for (int b = 0; b < B; ++b) {
+        bool any = false;
+        for (int wave = 0; wave < wpg && !any; ++wave)
+            for (int i = 0; i < K; ++i) {
+                const int64_t s = sw_slot_of(wg, wave, i, nwg, wpg);
+                if (s < ns && scnt[s * B + b]) { any = true; break; }
+            }
+        if (any) out[1 + cnt++] = (uint32_t)b;
+    }
+    out[0] = cnt;
+}
 // pass 4: the entry stream.  One wave per slot; lane l writes the words of ITS row (8 bytes each, 512 contiguous bytes
 // per wave and word-row).
 __global__ __launch_bounds__(256) void k_sw_fill(int32_t n_sw, int32_t ns, int nwg, int wpg, int B, int BN, const int32_t *__restrict__ order,
@@ -187,7 +209,8 @@ __global__ __launch_bounds__(512) void k_sweep_lds(int32_t n, int32_t n_sw, int 
                                                     const uint2 *__restrict__ ents, const double *__restrict__ z,
                                                     const int32_t *__restrict__ order, double *__restrict__ y,
                                                     const int32_t *__restrict__ seeds, int skip_seed_row, double c1,
-                                                    const double *__restrict__ w_src, double *__restrict__ zout)
+                                                    const double *__restrict__ w_src, double *__restrict__ zout,
+                                                    const uint32_t *__restrict__ wgblk)
 {
     extern __shared__ double zs[];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
@@ -228,11 +251,20 @@ __global__ __launch_bounds__(512) void k_sweep_lds(int32_t n, int32_t n_sw, int 
     double acc[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) acc[i] = 0.0;
-    // record of block 0: {first word-row of the wave's stream, piece lengths of slots 0..3, word-rows of the whole stream}
+    // the blocks this workgroup visits (workgroup-uniform: every wave walks the same list and meets the others at the same
+    // barriers); the records of all other blocks hold empty pieces for every wave of the workgroup
+    const uint32_t *wl = wgblk + (size_t)wg * (B + 1);
+    const int nb = (int)__builtin_amdgcn_readfirstlane(wl[0]);
+    ++wl;
+    // record of block 0: {first word-row of the wave's stream, ..., word-rows of the whole stream}; then the first visited block's
     const uint4 m0 = mrow[0];
     const uint32_t T = __builtin_amdgcn_readfirstlane(m0.w);
-    uint32_t my = __builtin_amdgcn_readfirstlane(m0.y), mz = __builtin_amdgcn_readfirstlane(m0.z);
-    uint4 mn = mrow[B > 1 ? 1 : 0];
+    int kb = 0;                                                        // position in the list of visited blocks
+    int b = nb > 0 ? (int)__builtin_amdgcn_readfirstlane(wl[0]) : 0;
+    const uint4 mc = mrow[b];
+    uint32_t my = __builtin_amdgcn_readfirstlane(mc.y), mz = __builtin_amdgcn_readfirstlane(mc.z);
+    int bn = nb > 1 ? (int)__builtin_amdgcn_readfirstlane(wl[1]) : b;  // the next visited block and its record, fetched one block ahead
+    uint4 mn = mrow[bn];
     typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint2 *>(ents + (size_t)__builtin_amdgcn_readfirstlane(m0.x) * WAVE), (short)0, (int)(T * (WAVE * 8u)), 0x00020000);
@@ -241,11 +273,11 @@ __global__ __launch_bounds__(512) void k_sweep_lds(int32_t n, int32_t n_sw, int 
 #pragma unroll
     for (int u = 0; u < SW_D; ++u) r[u] = __builtin_amdgcn_raw_buffer_load_b64(srs, lane8, (int)(u * (WAVE * 8u)), SW_STREAM_AUX);
 
-    int b = 0, i = 0;
+    int i = 0;
     const double *zc = zs;
     uint32_t pend = my & 0xffffu;                                      // end (stream position) of the current piece
     double a = 0.0;
-    SW_ENTER_BLOCK()
+    if (nb > 0) SW_ENTER_BLOCK()
 
 #define SW_PIECE_LEN(I) ((((I) < 2 ? my : mz) >> (((I) & 1) * 16)) & 0xffffu)
     // the current piece (block b, slot i) is exhausted: park its sum, move to the next piece
@@ -255,15 +287,17 @@ __global__ __launch_bounds__(512) void k_sweep_lds(int32_t n, int32_t n_sw, int 
         ++i;                                                                                                  \
         if (i == K) {                                                                                         \
             i = 0;                                                                                            \
-            ++b;                                                                                              \
-            if (b < B) {                                                                                      \
+            ++kb;                                                                                             \
+            if (kb < nb) {                                                                                    \
+                b = bn;                                                                                       \
                 my = __builtin_amdgcn_readfirstlane(mn.y);                                                    \
                 mz = __builtin_amdgcn_readfirstlane(mn.z);                                                    \
-                mn = mrow[b + 1 < B ? b + 1 : B - 1];                                                         \
+                bn = (int)__builtin_amdgcn_readfirstlane(wl[kb + 1 < nb ? kb + 1 : nb - 1]);                  \
+                mn = mrow[bn];                                                                                \
                 SW_ENTER_BLOCK()                                                                              \
             }                                                                                                 \
         }                                                                                                     \
-        if (b < B) {                                                                                          \
+        if (kb < nb) {                                                                                        \
             _Pragma("unroll") for (int q__ = 0; q__ < K; ++q__) if (i == q__) a = acc[q__];                   \
             pend += SW_PIECE_LEN(i);                                                                          \
         }                                                                                                     \
@@ -293,7 +327,7 @@ __global__ __launch_bounds__(512) void k_sweep_lds(int32_t n, int32_t n_sw, int 
             _Pragma("unroll") for (int u = 0; u < SW_G; ++u) {                                                            \
                 const uint32_t tt = t0 + u;                                                                               \
                 if (tt < T) {                                                                                             \
-                    while (tt == pend && b < B) SW_ADVANCE()                                                              \
+                    while (tt == pend && kb < nb) SW_ADVANCE()                                                            \
                     const v2u_t w = r[(GQ) * SW_G + u];                                                                   \
                     const double v0 = zc[w.x & 0xffffu], v1 = zc[w.x >> 16], v2 = zc[w.y & 0xffffu], v3 = zc[w.y >> 16];  \
                     a += v0; a += v1; a += v2; a += v3;                                                                   \
@@ -315,7 +349,7 @@ __global__ __launch_bounds__(512) void k_sweep_lds(int32_t n, int32_t n_sw, int 
     if (pending) SW_FLUSH(vb)                                          // (the last group of an iteration writes vb)
 #undef SW_GROUP
 #undef SW_FLUSH
-    while (b < B) SW_ADVANCE()                                         // the pieces behind the stream's end are all empty
+    while (kb < nb) SW_ADVANCE()                                       // the pieces behind the stream's end are all empty
 #undef SW_PIECE_LEN
 #undef SW_ADVANCE
 #undef SW_ENTER_BLOCK
@@ -358,33 +392,45 @@ int32_t sweep_prepare(rwr_graph *g)
     const int wpg = 8;                                     // waves per workgroup (512 threads: up to 256 registers per lane)
     hipDeviceProp_t prop;
     RWR_HIP(hipGetDeviceProperties(&prop, g->device));
-    // workgroups of the sweep (one per CU, each holding its CU's LDS): a share of the CUs is left to the hub-row kernel, whose
-    // workgroups ask for more LDS than a CU has left beside a sweep workgroup and therefore land on the other CUs -- the two
-    // kernels then never share a SIMD (sharing one slowed both: 93 us beside 88 us standalone became 184 us together)
-    static const int wgs_env = [] { const char *e = RWR_TUNE_ENV("RWR_SWEEP_WGS"); return e ? atoi(e) : 0; }();
     const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int32_t n_hub = g->x_hub[0] + g->x_hub[1];
-    int nwg = wgs_env > 0 ? wgs_env : (n_hub > 0 ? (ncu * 5) / 8 : ncu);
-    if (nwg > ncu) nwg = ncu;
-    if (nwg < 1) nwg = 1;
-    const int nw = nwg * wpg;
     // sweep order: the two-phase in-degree order (engine.h: row_order_x -- ITEM rows, then the others, each by in-degree
     // descending) without its hub rows.  The 64 rows of a slot then gather from the same region of the rank vector (an
     // item's in-links come from users, a user's mostly from items): with the one-phase order a slot mixed both kinds, its
     // lanes were idle in half of the blocks and the stream held 2x padding.
-    const int32_t hub0 = g->x_hub[0] + g->x_hub[1];
-    const int32_t n_sw = g->n - hub0;
-    if (n_sw <= 0) return RWR_OK;
-    RWR_TRY(g->sw_order.ensure((size_t)n_sw));
-    {
-        const int32_t a0 = g->x_rows[0] - g->x_hub[0], a1 = g->x_rows[1] - g->x_hub[1];
-        if (a0 > 0) RWR_HIP(hipMemcpyAsync(g->sw_order.p, g->row_order_x.p + g->x_hub[0], (size_t)a0 * sizeof(int32_t), hipMemcpyDeviceToDevice, g->stream));
-        if (a1 > 0) RWR_HIP(hipMemcpyAsync(g->sw_order.p + a0, g->row_order_x.p + g->x_rows[0] + g->x_hub[1], (size_t)a1 * sizeof(int32_t), hipMemcpyDeviceToDevice, g->stream));
-    }
-    const int32_t ns = (int32_t)(((int64_t)n_sw + WAVE - 1) / WAVE);
-    const int K = (ns + nw - 1) / nw;
+    const int32_t a0 = g->x_rows[0] - g->x_hub[0], a1 = g->x_rows[1] - g->x_hub[1];
     const int B = (int)(((int64_t)g->n + BN - 1) / BN);
-    if (K > SW_MAXK || B > 512 || g->hub_t > SW_GR * 65535) return RWR_OK;   // (piece lengths are kept in 16 bits)
+    if (B > 512 || g->hub_t > SW_GR * 65535) return RWR_OK;             // (piece lengths are kept in 16 bits)
+    // workgroups of the sweep (one per CU, each holding its CU's LDS): a share of the CUs is left to the hub-row kernel, whose
+    // workgroups ask for more LDS than a CU has left beside a sweep workgroup and therefore land on the other CUs -- the two
+    // kernels then never share a SIMD (sharing one slowed both: 93 us beside 88 us standalone became 184 us together)
+    static const int wgs_env = [] { const char *e = getenv("RWR_SWEEP_WGS"); return e ? atoi(e) : 0; }();   // (tests: few workgroups force the ITEM-rows-only form on small graphs)
+    int nwg = wgs_env > 0 ? wgs_env : (n_hub > 0 ? (ncu * 5) / 8 : ncu);
+    if (nwg > ncu) nwg = ncu;
+    if (nwg < 1) nwg = 1;
+    int32_t n_sw = a0 + a1;
+    int partial = 0;
+    auto slots_of = [](int64_t rows) { return (int32_t)((rows + WAVE - 1) / WAVE); };
+    if ((slots_of(n_sw) + nwg * wpg - 1) / (nwg * wpg) > SW_MAXK) {
+        // too many rows for SW_MAXK slots per wave.  The ITEM rows alone may still fit -- and on a bipartite like-graph they
+        // are the rows whose sources (the users) span few blocks, so their share of the step costs a handful of refills; the
+        // other rows (users gathering from the far larger item range) stay with the row-binned kernel, which runs BESIDE
+        // the sweep (spmv.hip).  Measured on the 0.6 M-node graph: 127 us for the binned kernel alone.
+        const int need = (slots_of(a0) + wpg * SW_MAXK - 1) / (wpg * SW_MAXK);   // workgroups for at most SW_MAXK slots per wave
+        if (a0 <= 0 || a1 <= 0 || need > ncu) return RWR_OK;
+        partial = 1;
+        n_sw = a0;
+        if (nwg < need) nwg = need;
+    }
+    if (n_sw <= 0) return RWR_OK;
+    const int nw = nwg * wpg;
+    RWR_TRY(g->sw_order.ensure((size_t)n_sw));
+    if (a0 > 0) RWR_HIP(hipMemcpyAsync(g->sw_order.p, g->row_order_x.p + g->x_hub[0], (size_t)a0 * sizeof(int32_t), hipMemcpyDeviceToDevice, g->stream));
+    if (a1 > 0 && !partial) RWR_HIP(hipMemcpyAsync(g->sw_order.p + a0, g->row_order_x.p + g->x_rows[0] + g->x_hub[1], (size_t)a1 * sizeof(int32_t), hipMemcpyDeviceToDevice, g->stream));
+    const int32_t hub0 = n_hub;
+    const int32_t ns = slots_of(n_sw);
+    const int K = (ns + nw - 1) / nw;
+    if (K > SW_MAXK) return RWR_OK;
     hipStream_t s = g->stream;
     DevBuf<uint32_t> scnt, woff, tot, base;
     DevBuf<unsigned long long> total;
@@ -394,28 +440,42 @@ int32_t sweep_prepare(rwr_graph *g)
     RWR_TRY(base.alloc(nw));
     RWR_TRY(total.alloc(1));
     RWR_TRY(g->sw_meta.ensure((size_t)nw * B));
+    RWR_TRY(g->sw_wgblk.ensure((size_t)nwg * (B + 1)));
     const int32_t *order = g->sw_order.p;
     hipLaunchKernelGGL(k_sw_count, dim3(cdiv((size_t)ns, 4)), dim3(256), 0, s, n_sw, ns, B, BN, order, g->in_ptr.p, g->in_src.p, scnt.p);
     hipLaunchKernelGGL(k_sw_wave_prefix, dim3(cdiv((size_t)nw, 256)), dim3(256), 0, s, nw, nwg, wpg, K, ns, B, scnt.p, woff.p, tot.p);
     hipLaunchKernelGGL(k_sw_scan, dim3(1), dim3(1024), 0, s, nw, tot.p, base.p, total.p);
     hipLaunchKernelGGL(k_sw_meta, dim3(cdiv((size_t)nw * B, 256)), dim3(256), 0, s, nw, nwg, wpg, K, ns, B, scnt.p, woff.p, base.p,
                        tot.p, g->sw_meta.p);
+    hipLaunchKernelGGL(k_sw_wglist, dim3(cdiv((size_t)nwg, 64)), dim3(64), 0, s, nwg, wpg, K, ns, B, scnt.p, g->sw_wgblk.p);
     RWR_HIP(hipGetLastError());
     unsigned long long h_total = 0;
+    std::vector<uint32_t> h_flags;
     RWR_HIP(hipMemcpyAsync(&h_total, total.p, sizeof(h_total), hipMemcpyDeviceToHost, s));
+    if (partial) {
+        h_flags.resize((size_t)nwg * (B + 1));
+        RWR_HIP(hipMemcpyAsync(h_flags.data(), g->sw_wgblk.p, h_flags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
     RWR_HIP(hipStreamSynchronize(s));
     if (h_total >= 0xFFFFFFFFull) return RWR_OK;            // word-row offsets are 32-bit
+    if (partial) {
+        // worth it only while the ITEM rows read few blocks (each refill costs every workgroup ~2.5 us)
+        size_t refills = 0;
+        for (int w = 0; w < nwg; ++w) refills += h_flags[(size_t)w * (B + 1)];
+        if (refills > (size_t)16 * nwg) return RWR_OK;
+    }
     RWR_TRY(g->sw_ent.ensure((size_t)h_total * WAVE + WAVE));
     hipLaunchKernelGGL(k_sw_fill, dim3(cdiv((size_t)ns, 4)), dim3(256), 0, s, n_sw, ns, nwg, wpg, B, BN, order, g->in_ptr.p, g->in_src.p,
                        g->sw_meta.p, g->sw_ent.p);
     RWR_HIP(hipGetLastError());
     RWR_HIP(hipStreamSynchronize(s));
     g->sw_B = B; g->sw_BN = BN; g->sw_K = K; g->sw_nwg = nwg; g->sw_wpg = wpg; g->sw_hub0 = hub0;
+    g->sw_rows = n_sw; g->sw_partial = partial;
     g->sw_words = (int64_t)h_total * WAVE;
     g->sw_state = 1;
 #ifdef RWR_EXPERIMENTS
-    fprintf(stderr, "[sweep] n %d hubs %d slots %d K %d blocks %d (BN %d) compute waves %d x %d words %lld (%.1f MB) nnz %lld\n", g->n, hub0, ns, K, B,
-            BN, nwg, wpg, (long long)g->sw_words, g->sw_words * 8 / 1e6, (long long)g->nnz);
+    fprintf(stderr, "[sweep] n %d hubs %d rows %d%s slots %d K %d blocks %d (BN %d) compute waves %d x %d words %lld (%.1f MB) nnz %lld\n", g->n, hub0,
+            n_sw, partial ? " (ITEM rows only)" : "", ns, K, B, BN, nwg, wpg, (long long)g->sw_words, g->sw_words * 8 / 1e6, (long long)g->nnz);
 #endif
     return RWR_OK;
 }
@@ -426,7 +486,7 @@ bool sweep_ready(const rwr_graph *g) { return g->sw_state == 1; }
 void launch_sweep(rwr_graph *g, const double *zin, double *Y, double *zout, const int32_t *seeds, int skip, double c1, hipStream_t s)
 {
     const size_t smem = ((size_t)g->sw_BN + 2) * sizeof(double);
-    const int32_t n_sw = g->n - g->sw_hub0;
+    const int32_t n_sw = g->sw_rows;
     const int32_t *order = g->sw_order.p;
     const uint4 *meta = g->sw_meta.p;
     const uint2 *ents = g->sw_ent.p;
@@ -444,7 +504,7 @@ void launch_sweep(rwr_graph *g, const double *zin, double *Y, double *zout, cons
     {                                                                                                                              \
         (void)hipFuncSetAttribute((const void *)k_sweep_lds<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);           \
         hipLaunchKernelGGL(k_sweep_lds<KK>, dim3(g->sw_nwg), dim3(g->sw_wpg * WAVE), smem, s, g->n, n_sw, g->sw_B,                \
-                           g->sw_BN, meta, ents, zin, order, Y, seeds, skip, c1, g->w_src.p, zout);                                \
+                           g->sw_BN, meta, ents, zin, order, Y, seeds, skip, c1, g->w_src.p, zout, g->sw_wgblk.p);               \
     }
     switch (g->sw_K) {
         case 1: RWR_SWEEP(1) break;

@@ -10,7 +10,9 @@ process (tests/env_child.py) and compared with the C restatement of the referenc
   small.hip -- both must equal the oracle bit for bit;
 * the source-block sweep of the single-seed SpMV (sweep.hip), which by default serves graphs of >= 50 000 nodes only:
   RWR_SWEEP_MIN_N=0 sends the oracle-sized graphs through it, RWR_SWEEP_BN shrinks the LDS block so that they span many
-  blocks, RWR_HUB_T lowers the hub-row threshold so that hub kernel and sweep share the rows of one step;
+  blocks, RWR_HUB_T lowers the hub-row threshold so that hub kernel and sweep share the rows of one step, RWR_SWEEP_WGS
+  leaves the sweep so few workgroups that it can only take the ITEM rows (its form on graphs of more than ~0.5 M rows) and
+  skips the blocks they do not read, with the other rows on the row-binned kernel beside it;
 * the frontier iterations of a single seed (rows none of whose in-neighbours is non-zero are skipped), which by default
   only graphs of >= 200 000 nodes take: RWR_ACT_ITERS forces them, with RWR_HUB_T low enough that hub rows are among the
   skipped and the walked ones."""
@@ -42,6 +44,8 @@ def run_child(env_extra):
     {"RWR_SWEEP_MIN_N": "0", "RWR_SMALL": "0"},
     {"RWR_SWEEP_MIN_N": "0", "RWR_SMALL": "0", "RWR_SWEEP_BN": "512"},
     {"RWR_SWEEP_MIN_N": "0", "RWR_SMALL": "0", "RWR_SWEEP_BN": "128", "RWR_HUB_T": "96"},
+    {"RWR_SWEEP_MIN_N": "0", "RWR_SMALL": "0", "RWR_SWEEP_WGS": "4"},
+    {"RWR_SWEEP_MIN_N": "0", "RWR_SMALL": "0", "RWR_SWEEP_WGS": "3", "RWR_SWEEP_BN": "512", "RWR_HUB_T": "96"},
     {"RWR_SWEEP": "0"},
     {"RWR_SMALL": "0", "RWR_ACT_ITERS": "2", "RWR_HUB_T": "96"},
     {"RWR_SMALL": "0", "RWR_ACT_ITERS": "2", "RWR_HUB_T": "96", "RWR_VALUE_FREE": "0"},
