@@ -279,6 +279,19 @@ __device__ double cs_redo_block(double s, int32_t n, int nchunks, int c, int til
         lb = lo;
     }
     const bool haslink = lb < a1 && (int64_t)srcp[lb] < row0 + R;
+    // the run's links into the seed, fetched ONCE (row within the run, addend): every pass below walks the run again, and
+    // chasing srcp[q] / the term through global memory row by row cost a lane with a link ~1.5 us per row and pass
+    constexpr int LK = 4;
+    int lu[LK] = {-1, -1, -1, -1};
+    double lt[LK] = {0.0, 0.0, 0.0, 0.0};
+    bool many = false;                                          // more than LK links in this run: the loops below go to memory
+    if (haslink) {
+        int32_t q = lb;
+#pragma unroll
+        for (int k = 0; k < LK; ++k)
+            if (q < a1 && (int64_t)srcp[q] < row0 + R) { lu[k] = (int)((int64_t)srcp[q] - row0); lt[k] = cs_term(termp, zt, srcp, q, G); ++q; }
+        many = q < a1 && (int64_t)srcp[q] < row0 + R;
+    }
 #pragma unroll
     for (int u = 0; u < R; ++u) nzl = nzl || red_a[lane * R + u + ((lane * R + u) >> 6)] != 0.0;
     nzl = nzl || haslink;
@@ -298,8 +311,12 @@ __device__ double cs_redo_block(double s, int32_t n, int nchunks, int c, int til
                 int32_t q = lb;
 #pragma unroll
                 for (int u = 0; u < R; ++u) {
-                    if (haslink)
+                    if (many) {
                         while (q < a1 && (int64_t)srcp[q] == row0 + u) { f = pf_compose(f, pf_of(cs_term(termp, zt, srcp, q, G), eb)); ++q; }
+                    } else if (haslink) {
+#pragma unroll
+                        for (int k = 0; k < LK; ++k) if (lu[k] == u) f = pf_compose(f, pf_of(lt[k], eb));   // list order (Model.cs:85-88)
+                    }
                     f = pf_compose(f, pf_of(red_a[lane * R + u + ((lane * R + u) >> 6)], eb));
                 }
             }
@@ -325,8 +342,12 @@ __device__ double cs_redo_block(double s, int32_t n, int nchunks, int c, int til
             int32_t q = lb;
 #pragma unroll
             for (int u = 0; u < R; ++u) {
-                if (haslink)
+                if (many) {
                     while (q < a1 && (int64_t)srcp[q] == row0 + u) { t += cs_term(termp, zt, srcp, q, G); ++q; }   // Model.cs:85-88
+                } else if (haslink) {
+#pragma unroll
+                    for (int k = 0; k < LK; ++k) if (lu[k] == u) t += lt[k];
+                }
                 t += red_a[lane * R + u + ((lane * R + u) >> 6)];                              // Model.cs:91-93,96-97
             }
         }
