@@ -92,11 +92,11 @@ def test_split_blocks_are_exact_or_refused():
         if ((m.bits(want) >> 52) & 0x7FF) != eb + 1:
             continue
         # the prediction: exact, or off by a few thousand ulps either way, or grossly off
-        err = rng.choice([0.0, 1e-13, -1e-13, 3e-12, -3e-12, 1e-6, -1e-6])
+        err = rng.choice([0.0, 1e-13, -1e-13, 3e-12, -3e-12, 1e-6, -1e-6, 2e-3, -2e-3, 3e-2, -3e-2])
         pre = s * (1.0 + err)
         if ((m.bits(pre) >> 52) & 0x7FF) != eb:
             continue
-        sp = m.split_block(pre, block)
+        sp = m.split_block(pre, block, run=rng.choice([4, 8]))     # (4: the chain's blocks, 8: the hub rows' segments -- spmv.hip)
         got = m.apply_split(s, sp)
         if got is None:
             refused += 1
