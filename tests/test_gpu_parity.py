@@ -437,6 +437,44 @@ def test_eval_graphs_batch_bitwise(amd):
     assert (h3 == hits[:3]).all()
 
 
+def test_eval_graphs_from_concurrent_host_threads(amd):
+    """rwr_eval_graphs from several host threads at once (the harness's threads each own an ego network, Program.cs:11): every
+    call's results equal those of the same batch evaluated alone.  The threads share the device-memory cache, the pool of
+    pinned sets and the pool of streams."""
+    import threading
+    rng = np.random.default_rng(23)
+    batches = []
+    for t in range(5):
+        graphs, seeds, tests = [], [], []
+        for k in range(7 + t):
+            g = gg.random_graph(700 + 20 * t + k, n_users=int(rng.integers(30, 300)), n_items=int(rng.integers(50, 1800)),
+                                n_likes=int(rng.integers(300, 6000)), n_friend=int(rng.integers(0, 200)), n_mention=int(rng.integers(0, 100)))
+            graphs.append(amd.Graph.from_flat(**g))
+            seeds.append(int(rng.integers(0, 30)))
+            ids = g["node_id"][g["node_type"] == gg.NODE_ITEM]
+            tests.append(rng.choice(ids, min(len(ids), 25), replace=False).tolist())
+        batches.append((graphs, seeds, tests))
+    alone = [amd.EvaluateGraphs(gs, sd, 0.15, 9, ts) for gs, sd, ts in batches]
+    errors, got = [], [None] * len(batches)
+
+    def worker(t):
+        try:
+            gs, sd, ts = batches[t]
+            for _ in range(6):
+                got[t] = amd.EvaluateGraphs(gs, sd, 0.15, 9, ts)
+        except Exception as e:                                   # pragma: no cover
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(len(batches))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(300)
+    assert not errors, errors
+    for (h, sp, ln), (h2, sp2, ln2) in zip(alone, got):
+        assert (h == h2).all() and (sp.view(np.uint64) == sp2.view(np.uint64)).all() and (ln == ln2).all()
+
+
 def test_cpp_host_mirror_runs_the_kats():
     """include/recommenders/rwr_based.hpp + tests/cpp/experiment_like.cpp: the caller pattern of
     Experiment.cs:104-128 in C++ against librwr (built by __graft_entry__.build())."""
