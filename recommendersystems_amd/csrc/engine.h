@@ -115,6 +115,7 @@ struct rwr_graph {
 
     // row-partitioned mode (rwr_part_*)
     int32_t part_lo = 0, part_hi = 0, part_G = 0, part_K = 0;
+    int32_t part_steps = 0;           // slab steps since rwr_part_begin (the first ones mark the frontier, like the seed path)
     double part_c1 = 0;
     std::vector<int32_t> part_seeds;
 

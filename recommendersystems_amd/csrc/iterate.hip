@@ -624,6 +624,24 @@ __global__ __launch_bounds__(256) void k_make_z(int64_t elems, int G, const doub
     Z[q] = rw * w_src[q / G];
 }
 
+// row-partitioned mode, first steps: z of the slab's rows AND the bitmap of the rows that hold a non-zero (global row numbers).
+// (only while the ranks are still sparse: one atomic per non-zero row)
+__global__ __launch_bounds__(256) void k_make_z_nz(int64_t rows, int G, int32_t lo, const double *__restrict__ Xs, double *__restrict__ Z,
+                                                   const double *__restrict__ w_src_s, double c1, uint32_t *__restrict__ nz)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;         // row of the slab
+    if (i >= rows) return;
+    bool any = false;
+    const double w = w_src_s[i];
+    for (int k = 0; k < G; ++k) {
+        const double xv = Xs[(size_t)i * G + k];
+        const double rw = c1 * xv;
+        Z[(size_t)i * G + k] = rw * w;
+        any = any || xv != 0.0;
+    }
+    if (any) { const int64_t j = (int64_t)lo + i; atomicOr(&nz[(uint32_t)j >> 5], 1u << (j & 31)); }
+}
+
 // ------------------------------------------------------------------------------ host side
 
 template <int G>
@@ -1451,6 +1469,8 @@ int32_t part_begin(rwr_graph *g, int32_t lo, int32_t hi, const int32_t *seeds, i
     if (g->vf) RWR_TRY(g->Z0.ensure((size_t)(hi - lo > 0 ? hi - lo : 1) * (size_t)G));
     else RWR_TRY(ensure_in_w(g));
     g->part_lo = lo; g->part_hi = hi; g->part_G = G; g->part_K = K; g->part_c1 = 1 - d;
+    g->part_steps = 0;
+    if (g->vf && g->nonneg && G >= 8) RWR_TRY(g->d_nz.ensure(2 * (((size_t)n + 31) / 32)));   // frontier of the first steps
     g->part_seeds.assign((size_t)G, -1);
     for (int32_t k = 0; k < K; ++k) g->part_seeds[k] = seeds[k];
     RWR_TRY(g->d_seeds.ensure(G));
@@ -1476,10 +1496,27 @@ static int32_t part_spmm(rwr_graph *g, const double *x, double *y, hipStream_t s
         const int64_t rows = (int64_t)g->part_hi - g->part_lo;
         if (rows > 0 && (!g->Z0.p || g->Z0.count < (size_t)rows * G)) { set_error("rwr_part_step: call rwr_part_begin"); return RWR_E_INVALID; }
         const int64_t elems = rows * G;
+        const double *zin = g->Z0.p - (size_t)g->part_lo * G;
+        // the first two steps after rwr_part_begin (the ranks are still concentrated around the seeds): mark the slab's non-zero
+        // rows and the destination rows their out-links reach, and let the SpMM skip every other row -- what the seed path
+        // does in its first iterations (GroupIter::init); exact for ANY rank matrix (a skipped row's addends are all +0.0),
+        // the step counter only decides whether marking is worth its cost
+        static const int part_act_env = [] { const char *e = RWR_TUNE_ENV("RWR_PART_ACT_STEPS"); return e ? atoi(e) : 2; }();
+        const size_t nzw = ((size_t)g->n + 31) / 32;
+        const bool frontier = g->part_steps < part_act_env && g->nonneg && G >= 8 && rows > 0 && g->d_nz.p && g->d_nz.count >= 2 * nzw;
+        ++g->part_steps;
+        if (frontier) {
+            uint32_t *nz = g->d_nz.p, *act = g->d_nz.p + nzw;
+            RWR_HIP(hipMemsetAsync(nz, 0, 2 * nzw * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(k_make_z_nz, dim3(cdiv((size_t)rows, 256)), dim3(256), 0, s, rows, G, g->part_lo, x + (size_t)g->part_lo * G,
+                               g->Z0.p, g->w_src.p + g->part_lo, c1, nz);
+            hipLaunchKernelGGL(k_mark_active, dim3(cdiv(nzw, 4), 1), dim3(256), 0, s, g->n, nz, act, g->rowptr.p, g->dst.p, g->etype.p);
+            RWR_DISPATCH_G(G, launch_spmm<GG>(g, 1, x, y, g->d_seeds.p, c1, 0, nz, nullptr, s, act, zin, nullptr, false));
+            return RWR_OK;
+        }
         if (elems > 0)
             hipLaunchKernelGGL(k_make_z, dim3(cdiv((size_t)elems, 256)), dim3(256), 0, s, elems, G, x + (size_t)g->part_lo * G, g->Z0.p,
                                g->w_src.p + g->part_lo, c1);
-        const double *zin = g->Z0.p - (size_t)g->part_lo * G;
         RWR_DISPATCH_G(G, launch_spmm<GG>(g, 1, x, y, g->d_seeds.p, c1, 0, nullptr, nullptr, s, nullptr, zin, nullptr, false));
     } else {
         if (!g->in_w.p) { set_error("rwr_part_step: call rwr_part_begin"); return RWR_E_INVALID; }
