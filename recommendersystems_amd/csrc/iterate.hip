@@ -625,21 +625,27 @@ __global__ __launch_bounds__(256) void k_make_z(int64_t elems, int G, const doub
 }
 
 // row-partitioned mode, first steps: z of the slab's rows AND the bitmap of the rows that hold a non-zero (global row numbers).
-// (only while the ranks are still sparse: one atomic per non-zero row)
-__global__ __launch_bounds__(256) void k_make_z_nz(int64_t rows, int G, int32_t lo, const double *__restrict__ Xs, double *__restrict__ Z,
-                                                   const double *__restrict__ w_src_s, double c1, uint32_t *__restrict__ nz)
+// A thread per row, counted from the 64-aligned row at or below the slab's first: a wave then covers exactly two words of the
+// bitmap and writes them whole (no atomics; the words of rows outside the slab stay as the memset left them).
+__global__ __launch_bounds__(256) void k_make_z_nz(int32_t lo, int32_t hi, int G, const double *__restrict__ X, double *__restrict__ Zs,
+                                                   const double *__restrict__ w_src, double c1, uint32_t *__restrict__ nz)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;         // row of the slab
-    if (i >= rows) return;
+    const int64_t j = ((int64_t)lo & ~(int64_t)63) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // global row
     bool any = false;
-    const double w = w_src_s[i];
-    for (int k = 0; k < G; ++k) {
-        const double xv = Xs[(size_t)i * G + k];
-        const double rw = c1 * xv;
-        Z[(size_t)i * G + k] = rw * w;
-        any = any || xv != 0.0;
+    if (j >= lo && j < hi) {
+        const double w = w_src[j];
+        const size_t at = (size_t)(j - lo) * G;
+        for (int k = 0; k < G; ++k) {
+            const double xv = X[(size_t)j * G + k];
+            const double rw = c1 * xv;
+            Zs[at + k] = rw * w;
+            any = any || xv != 0.0;
+        }
     }
-    if (any) { const int64_t j = (int64_t)lo + i; atomicOr(&nz[(uint32_t)j >> 5], 1u << (j & 31)); }
+    const unsigned long long m = __ballot(any);
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (lane == 0 && (uint32_t)m) nz[(uint64_t)j >> 5] = (uint32_t)m;
+    if (lane == 32 && (uint32_t)(m >> 32)) nz[(uint64_t)j >> 5] = (uint32_t)(m >> 32);
 }
 
 // ------------------------------------------------------------------------------ host side
@@ -1497,21 +1503,24 @@ static int32_t part_spmm(rwr_graph *g, const double *x, double *y, hipStream_t s
         if (rows > 0 && (!g->Z0.p || g->Z0.count < (size_t)rows * G)) { set_error("rwr_part_step: call rwr_part_begin"); return RWR_E_INVALID; }
         const int64_t elems = rows * G;
         const double *zin = g->Z0.p - (size_t)g->part_lo * G;
-        // the first two steps after rwr_part_begin (the ranks are still concentrated around the seeds): mark the slab's non-zero
-        // rows and the destination rows their out-links reach, and let the SpMM skip every other row -- what the seed path
-        // does in its first iterations (GroupIter::init); exact for ANY rank matrix (a skipped row's addends are all +0.0),
-        // the step counter only decides whether marking is worth its cost
+        // the first steps after rwr_part_begin (the ranks are still concentrated around the seeds): mark the slab's non-zero rows
+        // and -- the first two steps -- the destination rows their out-links reach, and let the SpMM skip every other row and
+        // every gather of an all-zero source row: what the seed path does in its first iterations (GroupIter::init); exact
+        // for ANY rank matrix (a skipped addend is +0.0), the step counter only decides whether the marking is worth its cost
         static const int part_act_env = [] { const char *e = RWR_TUNE_ENV("RWR_PART_ACT_STEPS"); return e ? atoi(e) : 2; }();
+        static const int part_nz_env = [] { const char *e = RWR_TUNE_ENV("RWR_PART_NZ_STEPS"); return e ? atoi(e) : 4; }();
         const size_t nzw = ((size_t)g->n + 31) / 32;
-        const bool frontier = g->part_steps < part_act_env && g->nonneg && G >= 8 && rows > 0 && g->d_nz.p && g->d_nz.count >= 2 * nzw;
+        const bool frontier = g->part_steps < part_nz_env && g->nonneg && G >= 8 && rows > 0 && g->d_nz.p && g->d_nz.count >= 2 * nzw;
+        const bool mark = frontier && g->part_steps < part_act_env;      // (later steps: only the per-entry probe of the sources)
         ++g->part_steps;
         if (frontier) {
             uint32_t *nz = g->d_nz.p, *act = g->d_nz.p + nzw;
-            RWR_HIP(hipMemsetAsync(nz, 0, 2 * nzw * sizeof(uint32_t), s));
-            hipLaunchKernelGGL(k_make_z_nz, dim3(cdiv((size_t)rows, 256)), dim3(256), 0, s, rows, G, g->part_lo, x + (size_t)g->part_lo * G,
-                               g->Z0.p, g->w_src.p + g->part_lo, c1, nz);
-            hipLaunchKernelGGL(k_mark_active, dim3(cdiv(nzw, 4), 1), dim3(256), 0, s, g->n, nz, act, g->rowptr.p, g->dst.p, g->etype.p);
-            RWR_DISPATCH_G(G, launch_spmm<GG>(g, 1, x, y, g->d_seeds.p, c1, 0, nz, nullptr, s, act, zin, nullptr, false));
+            RWR_HIP(hipMemsetAsync(nz, 0, (mark ? 2 : 1) * nzw * sizeof(uint32_t), s));
+            const int64_t first = (int64_t)g->part_lo & ~(int64_t)63;
+            hipLaunchKernelGGL(k_make_z_nz, dim3(cdiv((size_t)((int64_t)g->part_hi - first), 256)), dim3(256), 0, s, g->part_lo, g->part_hi, G, x,
+                               g->Z0.p, g->w_src.p, c1, nz);
+            if (mark) hipLaunchKernelGGL(k_mark_active, dim3(cdiv(nzw, 4), 1), dim3(256), 0, s, g->n, nz, act, g->rowptr.p, g->dst.p, g->etype.p);
+            RWR_DISPATCH_G(G, launch_spmm<GG>(g, 1, x, y, g->d_seeds.p, c1, 0, nz, nullptr, s, mark ? act : nullptr, zin, nullptr, false));
             return RWR_OK;
         }
         if (elems > 0)
