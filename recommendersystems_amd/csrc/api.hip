@@ -572,14 +572,11 @@ int32_t rwr_eval_graphs(int32_t count, const rwr_graph_desc *graphs, const int32
             const double q0 = now_ms();
             double q1 = 0, q2 = 0, q3 = 0;
 #endif
-            rc = rwr::graphs_build_multi(gs.data(), nc, descs.data(), kit.stream);
+            rc = rwr::graphs_build_multi(gs.data(), nc, descs.data(), fast.data() + c0, kit.stream);
 #ifdef RWR_EXPERIMENTS
             q1 = now_ms();
 #endif
-            if (rc != RWR_OK) {
-                // (the message names the position inside the chunk: translate to the caller's numbering)
-                break;
-            }
+            if (rc != RWR_OK) break;
             // the one-launch call takes the graphs that pass its own limits (items, links, the seed's in-list)
             std::vector<rwr_graph *> run;
             std::vector<int32_t> run_seed, run_at;

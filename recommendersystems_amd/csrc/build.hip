@@ -1028,8 +1028,7 @@ int32_t ensure_in_w(rwr_graph *g)
 // graph per call that is two synchronisations and a dozen runtime calls per graph, and the threads queue up behind the
 // runtime rather than the GPU.  Here every graph of the batch gets a workgroup of k_build_small_multi: one H2D copy of all
 // staging slots, one launch, one synchronisation.
-//   fits[i] = 0: graph i does not qualify for the one-launch build (the caller builds it the ordinary way); its handle
-//   is left untouched.
+//   caller_index[i]: the graph's number in the caller's batch (for error messages).
 // Pinned host buffers of one rwr_eval_graphs call, grown on demand: slot 0 the graphs' staging slots and read-back areas,
 // the others the small tables the batch kernels take (argument arrays, test sets, results).  Every host<->device copy of a
 // batch goes through pinned memory: an "asynchronous" copy from pageable memory is staged by the runtime under a process-wide
@@ -1080,7 +1079,7 @@ bool graph_fits_small_build(int32_t n, int64_t m)
     return stage_env && by_degree && n > 0 && n <= STAGE_MAX_N && m >= 0 && m <= STAGE_MAX_M;
 }
 
-int32_t graphs_build_multi(rwr_graph **gs, int32_t count, const rwr_graph_desc *descs, hipStream_t s)
+int32_t graphs_build_multi(rwr_graph **gs, int32_t count, const rwr_graph_desc *descs, const int32_t *caller_index, hipStream_t s)
 {
     if (count <= 0) return RWR_OK;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -1117,7 +1116,7 @@ int32_t graphs_build_multi(rwr_graph **gs, int32_t count, const rwr_graph_desc *
         const double u0 = bt_now();
 #endif
         RWR_TRY(graph_build_upload(g, D.node_id, D.node_type, D.rowptr, D.dst, D.etype, D.w));
-        if (!small_build_ok(g)) { set_error("graphs_build_multi: graph %d does not qualify for the one-launch build", i); return RWR_E_INVALID; }
+        if (!small_build_ok(g)) { set_error("graphs_build_multi: graph %d does not qualify for the one-launch build", caller_index[i]); return RWR_E_INVALID; }
 #ifdef RWR_EXPERIMENTS
         const double u1 = bt_now();
         mt_up += u1 - u0;
@@ -1152,7 +1151,7 @@ int32_t graphs_build_multi(rwr_graph **gs, int32_t count, const rwr_graph_desc *
         if (rc != RWR_OK) {
             char msg[512];
             snprintf(msg, sizeof(msg), "%s", rwr_last_error());
-            set_error("graph %d of the batch: %s", i, msg);
+            set_error("graph %d of the batch: %s", caller_index[i], msg);
             return rc;
         }
     }

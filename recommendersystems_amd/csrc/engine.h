@@ -151,7 +151,7 @@ bool graph_fits_small_build(int32_t n, int64_t m);
 void multi_pins_acquire();    // a set of pinned buffers for this thread's rwr_eval_graphs call (from a process-wide pool) ...
 void multi_pins_release();    // ... and back
 int32_t multi_pinned(int slot, size_t bytes, void **out);   // buffer number `slot` (0..5) of the acquired set, at least `bytes` long
-int32_t graphs_build_multi(rwr_graph **gs, int32_t count, const rwr_graph_desc *descs, hipStream_t s);
+int32_t graphs_build_multi(rwr_graph **gs, int32_t count, const rwr_graph_desc *descs, const int32_t *caller_index, hipStream_t s);
 int32_t recommend_small_multi(rwr_graph **gs, const int32_t *seeds, int32_t count, double d, int32_t n_iter, hipStream_t s,
                               rwr::DevBuf<uint8_t> &args_keep);
 int32_t eval_ranked_multi(rwr_graph **gs, int32_t count, const int64_t *test_ptr_host, const int64_t *test_sorted_host,

@@ -432,6 +432,10 @@ def test_eval_graphs_batch_bitwise(amd):
     Gb = amd.Graph.from_flat(**{k: bad[k] for k in ("node_id", "node_type", "rowptr", "dst", "etype", "w")})
     with pytest.raises(Exception, match="graph 1"):
         amd.EvaluateGraphs([Gs[0], Gb], seeds[:2], 0.15, 7, tests[:2])
+    # (the number is the caller's: graph 15 of this batch is beyond the one-launch build and is not among the graphs built
+    #  together, so the broken graph is number 16 for the caller but the 16th -- position 15 -- of that group)
+    with pytest.raises(Exception, match="graph 16"):
+        amd.EvaluateGraphs(Gs[:16] + [Gb], seeds[:16] + [seeds[0]], 0.15, 7, tests[:16] + [tests[0]])
     # ... and the library is usable afterwards
     h3, _, _ = amd.EvaluateGraphs(Gs[:3], seeds[:3], 0.15, 7, tests[:3])
     assert (h3 == hits[:3]).all()
