@@ -187,6 +187,8 @@ bool sweep_ready(const rwr_graph *g);
 void launch_sweep(rwr_graph *g, const double *zin, double *Y, double *zout, const int32_t *seeds, int skip, double c1,
                   hipStream_t s);
 // small.hip: ego-network-sized graphs, one single-seed Recommendation as ONE kernel launch (bitwise the EXACT path's result)
+void *small_pin_scratch(rwr_graph *g);   // the score half of the pinned result buffer (SM_MAX_ITEMS 8-byte words), as scratch
+int64_t small_pin_words();
 bool small_path_ok(const rwr_graph *g);
 bool small_path_seed_ok(const rwr_graph *g, int32_t seed);
 const int64_t *small_pin_ids(const rwr_graph *g);      // the list of the last recommend_small call, in pinned host memory

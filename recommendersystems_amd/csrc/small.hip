@@ -304,6 +304,9 @@ bool small_path_seed_ok(const rwr_graph *g, int32_t seed)
 // layout of the pinned result buffer recommend_small leaves behind (rwr_recommend copies the list out of it)
 const int64_t *small_pin_ids(const rwr_graph *g) { return reinterpret_cast<const int64_t *>(g->sm_pin); }
 const double *small_pin_scores(const rwr_graph *g) { return reinterpret_cast<const double *>(small_pin_ids(g) + SM_MAX_ITEMS); }
+// the score half of that buffer as scratch for an entry point that does not hand the list out (rank.hip: eval_ranked)
+void *small_pin_scratch(rwr_graph *g) { return reinterpret_cast<int64_t *>(g->sm_pin) + SM_MAX_ITEMS; }
+int64_t small_pin_words() { return SM_MAX_ITEMS; }
 
 bool small_path_ok(const rwr_graph *g)
 {

@@ -1,5 +1,5 @@
 // Host-thread scaling of rwr_eval_graphs without an interpreter in the way: T threads, each handing its own G synthetic
-// ego-network-sized graphs to one call, R times.  Build and run on the GPU box (tools/eval_graphs_threads.sh):
+// ego-network-sized graphs to one call, R times (third argument 1: the same graphs one per call -- create, recommend_eval, destroy).  Build and run on the GPU box (tools/eval_graphs_threads.sh):
 //   g++ -O2 -std=c++17 -pthread -Iinclude tools/eval_graphs_threads.cpp -o /tmp/egt recommendersystems_amd/librwr.so -Wl,-rpath,$PWD/recommendersystems_amd
 #include <chrono>
 #include <cstdint>
@@ -48,6 +48,7 @@ static HostGraph make_graph(unsigned seed)
 int main(int argc, char **argv)
 {
     const int G = argc > 1 ? atoi(argv[1]) : 19, R = argc > 2 ? atoi(argv[2]) : 40;
+    const bool single = argc > 3 && atoi(argv[3]) != 0;   // 1: one graph per call (create + recommend_eval + destroy), the unmodified harness's way
     const int maxT = 16;
     std::vector<HostGraph> graphs;
     for (int i = 0; i < maxT * G; ++i) graphs.push_back(make_graph(1000u + (unsigned)i));
@@ -65,6 +66,17 @@ int main(int argc, char **argv)
                 tp[(size_t)q + 1] = (int64_t)tids.size();
             }
             for (int r = 0; r < reps; ++r) {
+                if (single) {
+                    for (int q = 0; q < G; ++q) {
+                        rwr_graph *h = nullptr;
+                        int32_t rc = rwr_graph_create(d[q].n_nodes, d[q].node_id, d[q].node_type, d[q].rowptr, d[q].dst, d[q].etype, d[q].w, nullptr, &h);
+                        if (rc == RWR_OK)
+                            rc = rwr_recommend_eval(h, 0, 0.15f, 10, tids.data() + tp[q], tp[(size_t)q + 1] - tp[q], &hits[q], &sp[q], &len[q]);
+                        if (rc != RWR_OK) { fprintf(stderr, "single-graph calls: %s\n", rwr_last_error()); exit(1); }
+                        rwr_graph_destroy(h);
+                    }
+                    continue;
+                }
                 const int32_t rc = rwr_eval_graphs(G, d.data(), seeds.data(), 0.15f, 10, tp.data(), tids.data(), nullptr, hits.data(),
                                                    sp.data(), len.data());
                 if (rc != RWR_OK) { fprintf(stderr, "rwr_eval_graphs: %s\n", rwr_last_error()); exit(1); }
@@ -80,8 +92,8 @@ int main(int argc, char **argv)
         for (int t = 0; t < T; ++t) th.emplace_back(work, t, R);
         for (auto &x : th) x.join();
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        printf("{\"threads\": %d, \"graphs_per_call\": %d, \"graphs_per_s\": %.0f, \"ms_per_call\": %.3f}\n", T, G, (double)T * G * R / dt,
-               1e3 * dt / R);
+        printf("{\"threads\": %d, \"graphs_per_call\": %d, \"graphs_per_s\": %.0f, \"ms_per_call\": %.3f}\n", T, single ? 1 : G,
+               (double)T * G * R / dt, 1e3 * dt / R / (single ? G : 1));
         fflush(stdout);
     }
     return 0;
