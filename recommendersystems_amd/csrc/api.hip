@@ -677,9 +677,23 @@ int32_t rwr_recommend(rwr_graph *g, int32_t seed, float d, int32_t n_iter, int32
     int64_t width = (top_n > 0 && top_n < g->n_items) ? top_n : g->n_items;
     if (width == 0) { *inout_count = 0; return RWR_OK; }
     if (width > 0x7FFFFFFF) { set_error("rwr_recommend: list too long"); return RWR_E_UNSUPPORTED; }
+    int32_t cnt = 0;
+    if (width <= rwr::small_pin_words() && out_id && out_score && *inout_count >= width &&
+        !(rwr::small_path_ok(g) && rwr::small_path_seed_ok(g, seed))) {
+        // a short list (top-N of a large graph): count, ids and scores come back into the handle's pinned buffer behind ONE
+        // synchronisation (waiting for the count first and copying then cost a second host round trip: ~90 us of a 1.6 ms call)
+        RWR_TRY(rwr::small_pin_ensure(g));
+        int64_t *pid = const_cast<int64_t *>(rwr::small_pin_ids(g));
+        double *psc = const_cast<double *>(rwr::small_pin_scores(g));
+        g->sm_pin_count = -1;
+        RWR_TRY(recommend_batch(g, &seed, 1, (double)d, n_iter, (int32_t)width, pid, psc, &cnt, width));
+        memcpy(out_id, pid, sizeof(int64_t) * (size_t)cnt);
+        memcpy(out_score, psc, sizeof(double) * (size_t)cnt);
+        *inout_count = cnt;
+        return RWR_OK;
+    }
     // the ranked list stays on the device until its length is known, then goes straight into the caller's arrays
     // (no host staging copy: the full list of a 5 M-item graph is 80 MB)
-    int32_t cnt = 0;
     g->sm_pin_count = -1;
     RWR_TRY(recommend_batch(g, &seed, 1, (double)d, n_iter, (int32_t)width, nullptr, nullptr, &cnt, width));
     if (*inout_count < cnt || ((!out_id || !out_score) && cnt > 0)) {

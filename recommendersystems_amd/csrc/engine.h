@@ -187,6 +187,7 @@ bool sweep_ready(const rwr_graph *g);
 void launch_sweep(rwr_graph *g, const double *zin, double *Y, double *zout, const int32_t *seeds, int skip, double c1,
                   hipStream_t s);
 // small.hip: ego-network-sized graphs, one single-seed Recommendation as ONE kernel launch (bitwise the EXACT path's result)
+int32_t small_pin_ensure(rwr_graph *g);
 void *small_pin_scratch(rwr_graph *g);   // the score half of the pinned result buffer (SM_MAX_ITEMS 8-byte words), as scratch
 int64_t small_pin_words();
 bool small_path_ok(const rwr_graph *g);

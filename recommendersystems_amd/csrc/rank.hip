@@ -116,12 +116,57 @@ __global__ void k_sel_init(int nseg, int32_t top_n, const int32_t *__restrict__ 
     st[q] = s;
 }
 
+// one level's decision for one segment from its 256 digit counts h (cleared for the next level).  AGENT: the counts were
+// added by other workgroups of the running kernel (read with agent-scope loads); otherwise h is this workgroup's own memory
+template <bool AGENT>
+__device__ __forceinline__ void sel_decide(SelState &s, uint32_t *h, int level)
+{
+    auto cnt = [&](int b) -> uint32_t { return AGENT ? __hip_atomic_load(h + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : h[b]; };
+    if (s.done) return;
+    if (level == 0) {
+        int64_t tot = 0;
+        for (int b = 0; b < 256; ++b) tot += cnt(b);
+        s.total = (int32_t)tot;
+        if (tot <= s.k_rem) {                  // fewer candidates than top_n: take them all
+            s.k_rem = (int32_t)tot;
+            s.done = 1;                        // nbits stays 0: every key matches the empty prefix
+            for (int b = 0; b < 256; ++b) h[b] = 0;
+            return;
+        }
+    }
+    int64_t cum = 0;
+    int sel = 0;
+    uint32_t bin = 0;
+    for (int b = 255; b >= 0; --b) {
+        const uint32_t c = cnt(b);
+        if (cum + c >= (int64_t)s.k_rem) { sel = b; bin = c; break; }
+        cum += c;
+    }
+    for (int b = 0; b < 256; ++b) h[b] = 0;
+    s.k_rem -= (int32_t)cum;                   // entries above the chosen bin are all taken
+    if (level < 8) s.ph = (s.ph << 8) | (uint64_t)sel;
+    else s.pl = (s.pl << 8) | (uint64_t)sel;
+    s.nbits += 8;
+    if (bin <= (uint32_t)SEL_CAP || level == SEL_LEVELS - 1) s.done = 1;
+}
+// the digit of level `level` of a candidate's key, or -1 when it is excluded or lies outside the segment's prefix
+__device__ __forceinline__ int sel_digit(double sc, int32_t row, const int64_t *__restrict__ node_id, const SelState &my, int level)
+{
+    if (!(sc >= 0.0)) return -1;                                 // excluded (Recommender.cs:29)
+    const uint64_t hi = f64_orderable(sc);
+    uint64_t lo = 0;
+    if (level >= 8) lo = i64_orderable(node_id[row]);
+    if (sel_cmp(hi, lo, my) != 0) return -1;
+    return (level < 8) ? (int)((hi >> (56 - 8 * level)) & 255u) : (int)((lo >> (56 - 8 * (level - 8))) & 255u);
+}
+
 template <int G>
 __global__ __launch_bounds__(256) void k_sel_hist(int32_t n, int32_t n_items, const int32_t *__restrict__ item_rows,
                                                   const int64_t *__restrict__ node_id,
-                                                  const double *__restrict__ X, const SelState *__restrict__ st,
-                                                  uint32_t *__restrict__ ghist, int level)
+                                                  const double *__restrict__ X, SelState *__restrict__ st,
+                                                  uint32_t *__restrict__ ghist, int level, unsigned int *__restrict__ ticket)
 {
+    // ticket != nullptr: the workgroup that finishes LAST takes the level's decision for every segment (no k_sel_decide launch)
     constexpr int RL = 256 / G;
     // rows padded to 257 words: at one digit per seed (the usual case at the top levels) the G seeds of a wave would
     // otherwise all hit LDS bank (digit % 32) -- a G-way conflict on every atomic
@@ -137,14 +182,14 @@ __global__ __launch_bounds__(256) void k_sel_hist(int32_t n, int32_t n_items, co
         if (!sst[tid].done) any_active = 1;
     }
     __syncthreads();
-    if (!any_active) return;
+    if (!any_active && !ticket) return;
     for (int b = rl; b < 256; b += RL) h[k][b] = 0;
     __syncthreads();
     const double *x = X + (size_t)tile * (size_t)n * G;
     const SelState my = sst[k];
     const int32_t q0 = blockIdx.x * SEL_ROWS_PER_BLOCK;
     const int32_t q1 = (q0 + SEL_ROWS_PER_BLOCK < n_items) ? q0 + SEL_ROWS_PER_BLOCK : n_items;
-    if (!my.done) {
+    if (any_active && !my.done) {
         // 4 rows per trip: four independent (row index -> score) load chains in flight per thread
         for (int32_t qb = q0 + rl; qb < q1; qb += 4 * RL) {
             int32_t row[4];
@@ -158,17 +203,7 @@ __global__ __launch_bounds__(256) void k_sel_hist(int32_t n, int32_t n_items, co
             for (int u = 0; u < 4; ++u) sv[u] = x[(size_t)row[u] * G + k];
             int dg[4];                                           // digit of each of the 4 elements, -1 = not counted
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                dg[u] = -1;
-                if (qb + u * RL >= q1) continue;
-                const double s = sv[u];
-                if (!(s >= 0.0)) continue;                       // excluded (Recommender.cs:29)
-                const uint64_t hi = f64_orderable(s);
-                uint64_t lo = 0;
-                if (level >= 8) lo = i64_orderable(node_id[row[u]]);
-                if (sel_cmp(hi, lo, my) != 0) continue;
-                dg[u] = (level < 8) ? (int)((hi >> (56 - 8 * level)) & 255u) : (int)((lo >> (56 - 8 * (level - 8))) & 255u);
-            }
+            for (int u = 0; u < 4; ++u) dg[u] = (qb + u * RL >= q1) ? -1 : sel_digit(sv[u], row[u], node_id, my, level);
             // equal digits among the 4 (the rule at the top levels, where one exponent byte covers everything) are
             // counted with ONE LDS atomic: LDS atomics, not the loads, bound this kernel
 #pragma unroll
@@ -187,6 +222,71 @@ __global__ __launch_bounds__(256) void k_sel_hist(int32_t n, int32_t n_items, co
         const uint32_t c = h[k][b];
         if (c) atomicAdd(&ghist[((size_t)tile * G + k) * 256 + b], c);
     }
+    if (!ticket) return;
+    // the last workgroup to arrive decides (its own adds and everyone else's are complete and visible: fence + ticket)
+    __shared__ int last_s;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last_s = atomicAdd(&ticket[level], 1u) == gridDim.x * gridDim.y - 1u;
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    // (the 256 counts of a segment are fetched by the 256 threads at once -- one thread reading them one by one through
+    //  agent-scope loads took 10-50 us -- and cleared for the next level; the decision itself runs on the LDS copy)
+    const int nseg = (int)gridDim.y * G;
+    uint32_t *hc = &h[0][0];
+    for (int q = 0; q < nseg; ++q) {
+        uint32_t *gh = ghist + (size_t)q * 256;
+        hc[tid] = __hip_atomic_load(gh + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gh[tid] = 0;
+        __syncthreads();
+        if (tid == 0) {
+            SelState sq = st[q];
+            if (!sq.done) {
+                sel_decide<false>(sq, hc, level);
+                st[q] = sq;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Levels L0 .. 15 for ONE tile by one workgroup: by then the prefix holds L0 bytes of the key and the segment is almost
+// always decided (the bin of the k-th entry has at most SEL_CAP members) -- the kernel then ends at once, in place of
+// 2 * (16 - L0) launches that would find nothing to do; when a segment is NOT decided (a tie across thousands of scores)
+// the workgroup walks the tile's candidates itself, level by level.
+template <int G>
+__global__ __launch_bounds__(256) void k_sel_tail(int32_t n, int32_t n_items, const int32_t *__restrict__ item_rows,
+                                                  const int64_t *__restrict__ node_id, const double *__restrict__ X,
+                                                  SelState *__restrict__ st, int level0)
+{
+    constexpr int RL = 256 / G;
+    __shared__ uint32_t h[G][257];
+    __shared__ SelState sst[G];
+    __shared__ int any_active;
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x, k = tid % G, rl = tid / G;
+    const double *x = X + (size_t)tile * (size_t)n * G;
+    if (tid < G) sst[tid] = st[tile * G + tid];
+    for (int level = level0; level < SEL_LEVELS; ++level) {
+        if (tid == 0) any_active = 0;
+        __syncthreads();
+        if (tid < G && !sst[tid].done) any_active = 1;
+        for (int b = rl; b < 256; b += RL) h[k][b] = 0;
+        __syncthreads();
+        if (!any_active) break;                                  // (uniform)
+        const SelState my = sst[k];
+        if (!my.done)
+            for (int32_t q = rl; q < n_items; q += RL) {
+                const int32_t row = item_rows[q];
+                const int dg = sel_digit(x[(size_t)row * G + k], row, node_id, my, level);
+                if (dg >= 0) atomicAdd(&h[k][dg], 1u);
+            }
+        __syncthreads();
+        if (tid < G) sel_decide<false>(sst[tid], &h[tid][0], level);
+        __syncthreads();
+    }
+    if (tid < G) st[tile * G + tid] = sst[tid];
 }
 
 __global__ void k_sel_decide(int nseg, SelState *__restrict__ st, uint32_t *__restrict__ ghist, int level)
@@ -194,34 +294,8 @@ __global__ void k_sel_decide(int nseg, SelState *__restrict__ st, uint32_t *__re
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nseg) return;
     SelState s = st[q];
-    uint32_t *h = ghist + (size_t)q * 256;
     if (s.done) return;
-    if (level == 0) {
-        int64_t tot = 0;
-        for (int b = 0; b < 256; ++b) tot += h[b];
-        s.total = (int32_t)tot;
-        if (tot <= s.k_rem) {                  // fewer candidates than top_n: take them all
-            s.k_rem = (int32_t)tot;
-            s.done = 1;                        // nbits stays 0: every key matches the empty prefix
-            for (int b = 0; b < 256; ++b) h[b] = 0;
-            st[q] = s;
-            return;
-        }
-    }
-    int64_t cum = 0;
-    int sel = 0;
-    uint32_t bin = 0;
-    for (int b = 255; b >= 0; --b) {
-        const uint32_t c = h[b];
-        if (cum + c >= (int64_t)s.k_rem) { sel = b; bin = c; break; }
-        cum += c;
-    }
-    for (int b = 0; b < 256; ++b) h[b] = 0;
-    s.k_rem -= (int32_t)cum;                   // entries above the chosen bin are all taken
-    if (level < 8) s.ph = (s.ph << 8) | (uint64_t)sel;
-    else s.pl = (s.pl << 8) | (uint64_t)sel;
-    s.nbits += 8;
-    if (bin <= (uint32_t)SEL_CAP || level == SEL_LEVELS - 1) s.done = 1;
+    sel_decide<false>(s, ghist + (size_t)q * 256, level);
     st[q] = s;
 }
 
@@ -437,17 +511,34 @@ int32_t rank_group_select(rwr_graph *g, int G, int tg, const int32_t *d_slot_k, 
     const size_t st_bytes = (size_t)nseg * sizeof(SelState);
     const size_t hist_bytes = (size_t)nseg * 256 * sizeof(uint32_t);
     const size_t cand_bytes = (size_t)nseg * SEL_SLOTS * sizeof(SelCand);
-    RWR_TRY(g->sort_temp.ensure(st_bytes + hist_bytes + cand_bytes + 64));
+    const size_t ticket_bytes = SEL_LEVELS * sizeof(unsigned int);
+    RWR_TRY(g->sort_temp.ensure(st_bytes + hist_bytes + ticket_bytes + cand_bytes + 64));
     SelState *st = (SelState *)g->sort_temp.p;
     uint32_t *ghist = (uint32_t *)(g->sort_temp.p + st_bytes);
-    SelCand *cand = (SelCand *)(g->sort_temp.p + st_bytes + hist_bytes);
-    RWR_HIP(hipMemsetAsync(ghist, 0, hist_bytes, s));
+    unsigned int *ticket = (unsigned int *)(g->sort_temp.p + st_bytes + hist_bytes);
+    SelCand *cand = (SelCand *)(g->sort_temp.p + st_bytes + hist_bytes + ticket_bytes);
+    RWR_HIP(hipMemsetAsync(ghist, 0, hist_bytes + ticket_bytes, s));
     hipLaunchKernelGGL(k_sel_init, dim3(cdiv((size_t)nseg, 64)), dim3(64), 0, s, nseg, top_n, d_seeds, st);
     const unsigned nblk = cdiv((size_t)m, SEL_ROWS_PER_BLOCK);
-    for (int level = 0; level < SEL_LEVELS; ++level) {
-        RWR_DISPATCH_G(G, hipLaunchKernelGGL(k_sel_hist<GG>, dim3(nblk, tg), dim3(256), 0, s, g->n, m, g->item_rows.p,
-                                             g->node_id.p, X, st, ghist, level));
-        hipLaunchKernelGGL(k_sel_decide, dim3(cdiv((size_t)nseg, 64)), dim3(64), 0, s, nseg, st, ghist, level);
+    // A call of a few seeds is launch-bound: 16 levels x (histogram + decision) are 32 launches of which, typically, the
+    // first two or three find anything to do -- 0.35 of the 1.6 ms of a single-seed call on the 0.6 M-node graph.  There the
+    // decision is taken by the histogram kernel's last workgroup, and after SEL_FUSED_LEVELS levels ONE workgroup per tile
+    // finishes whatever is left (k_sel_tail).  Large batches keep the plain form (their launches are noise, and an undecided
+    // segment should not be walked by a single workgroup).
+    static const int fused_env = [] { const char *e = RWR_TUNE_ENV("RWR_SEL_FUSED"); return e ? atoi(e) : 1; }();
+    constexpr int SEL_FUSED_LEVELS = 3;
+    if (fused_env && nseg <= 64) {
+        for (int level = 0; level < SEL_FUSED_LEVELS; ++level)
+            RWR_DISPATCH_G(G, hipLaunchKernelGGL(k_sel_hist<GG>, dim3(nblk, tg), dim3(256), 0, s, g->n, m, g->item_rows.p,
+                                                 g->node_id.p, X, st, ghist, level, ticket));
+        RWR_DISPATCH_G(G, hipLaunchKernelGGL(k_sel_tail<GG>, dim3(tg), dim3(256), 0, s, g->n, m, g->item_rows.p, g->node_id.p, X, st,
+                                             SEL_FUSED_LEVELS));
+    } else {
+        for (int level = 0; level < SEL_LEVELS; ++level) {
+            RWR_DISPATCH_G(G, hipLaunchKernelGGL(k_sel_hist<GG>, dim3(nblk, tg), dim3(256), 0, s, g->n, m, g->item_rows.p,
+                                                 g->node_id.p, X, st, ghist, level, (unsigned int *)nullptr));
+            hipLaunchKernelGGL(k_sel_decide, dim3(cdiv((size_t)nseg, 64)), dim3(64), 0, s, nseg, st, ghist, level);
+        }
     }
     RWR_DISPATCH_G(G, hipLaunchKernelGGL(k_sel_collect<GG>, dim3(nblk, tg), dim3(256), 0, s, g->n, m, g->item_rows.p,
                                          g->node_id.p, X, st, d_seeds, cand));

@@ -304,6 +304,12 @@ bool small_path_seed_ok(const rwr_graph *g, int32_t seed)
 // layout of the pinned result buffer recommend_small leaves behind (rwr_recommend copies the list out of it)
 const int64_t *small_pin_ids(const rwr_graph *g) { return reinterpret_cast<const int64_t *>(g->sm_pin); }
 const double *small_pin_scores(const rwr_graph *g) { return reinterpret_cast<const double *>(small_pin_ids(g) + SM_MAX_ITEMS); }
+// makes sure the handle has its pinned result buffer (SM_MAX_ITEMS ids, SM_MAX_ITEMS scores, a count)
+int32_t small_pin_ensure(rwr_graph *g)
+{
+    if (!g->sm_pin) RWR_HIP(hipHostMalloc(&g->sm_pin, SM_MAX_ITEMS * 16 + 64, hipHostMallocMapped | hipHostMallocPortable));
+    return RWR_OK;
+}
 // the score half of that buffer as scratch for an entry point that does not hand the list out (rank.hip: eval_ranked)
 void *small_pin_scratch(rwr_graph *g) { return reinterpret_cast<int64_t *>(g->sm_pin) + SM_MAX_ITEMS; }
 int64_t small_pin_words() { return SM_MAX_ITEMS; }
@@ -334,9 +340,15 @@ int32_t recommend_small(rwr_graph *g, int32_t seed, double d, int32_t n_iter, in
     constexpr size_t smem = ((size_t)SM_MCAP + SM_MCAP / 64 + 64 + (size_t)SM_WAVES * 2 * WAVE) * sizeof(double) +
                             (size_t)SM_MAX_N * sizeof(int2);
     static_assert(smem >= (size_t)SM_MAX_ITEMS * sizeof(SmCand), "the sort re-uses the addend buffer");
-    if (!g->sm_pin) {
-        RWR_HIP(hipHostMalloc(&g->sm_pin, SM_MAX_ITEMS * 16 + 64, hipHostMallocMapped | hipHostMallocPortable));
-        RWR_HIP(hipFuncSetAttribute((const void *)k_small_rwr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    RWR_TRY(small_pin_ensure(g));
+    {   // the kernel's LDS attribute: once per device and process
+        static std::mutex attr_mu1;
+        static bool attr_done1[64];
+        std::lock_guard<std::mutex> lk(attr_mu1);
+        if (g->device >= 0 && g->device < 64 && !attr_done1[g->device]) {
+            RWR_HIP(hipFuncSetAttribute((const void *)k_small_rwr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr_done1[g->device] = true;
+        }
     }
     int64_t *pin_id = reinterpret_cast<int64_t *>(g->sm_pin);
     double *pin_score = reinterpret_cast<double *>(pin_id + SM_MAX_ITEMS);
