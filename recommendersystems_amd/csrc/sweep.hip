@@ -189,10 +189,7 @@ __global__ __launch_bounds__(256) void k_sw_fill(int32_t n_sw, int32_t ns, int n
 // gathers, then 16 dependent adds); a group that holds a piece end is walked word-row by word-row, switching accumulator
 // at a slot end and refilling LDS at a block end.
 constexpr int SW_D = 16;          // word-rows in flight per wave (8 KB)
-#ifndef RWR_SW_AUX
-#define RWR_SW_AUX 0
-#endif
-constexpr int SW_STREAM_AUX = RWR_SW_AUX;   // cache policy of the stream's loads (2 = nt: read once, do not displace z in the L2s)
+constexpr int SW_STREAM_AUX = 0;  // cache policy of the stream's loads (nt = 2, "read once, do not displace z in the L2s", measured: no difference)
 constexpr int SW_G = 4;           // word-rows per group
 
 #ifdef RWR_SWEEP_STAMPS   // compile-time option of the experiments build: per-wave cycle counts (tools/sweep_stamps.py)
