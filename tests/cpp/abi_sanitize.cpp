@@ -3,6 +3,7 @@
 //   hipcc ... -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined  (see tools/asan_run.sh)
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <random>
 #include <vector>
@@ -48,7 +49,7 @@ int main()
         rwr_opts o{};
         o.struct_size = sizeof(o);
         o.device = -1;
-        o.mode = round % 3 == 2 ? RWR_MODE_FAST : RWR_MODE_EXACT;
+        o.mode = RWR_MODE_EXACT;
         o.profile = round & 1;
         o.seed_row_kernel = round % 3;
         rwr_graph *g = nullptr;
@@ -80,6 +81,20 @@ int main()
         CHECK(rwr_recommend_eval(g, U / 2, 0.15f, 6, test.data(), (int64_t)test.size(), &hits, &sp, &ll));
         std::vector<double> rank(n), next(n);
         int64_t iters = 0;
+        {   // K seeds with K test sets (CSR), then the same graph three times through the many-graphs entry point
+            const int32_t es[3] = {0, U / 2, U - 1};
+            const int64_t tp[4] = {0, (int64_t)test.size() / 2, (int64_t)test.size() / 2, (int64_t)test.size()};
+            int64_t h3[3], l3[3]; double s3[3];
+            CHECK(rwr_recommend_eval_batch(g, es, 3, 0.15f, 6, tp, test.data(), h3, s3, l3));
+            rwr_graph_desc dd[3];
+            for (auto &D : dd) D = rwr_graph_desc{n, 0, id.data(), type.data(), rowptr.data(), dst.data(), et.data(), w.data()};
+            int64_t h4[3], l4[3]; double s4[3];
+            CHECK(rwr_eval_graphs(3, dd, es, 0.15f, 6, tp, test.data(), &o, h4, s4, l4));
+            for (int q = 0; q < 3; ++q)
+                if (h3[q] != h4[q] || l3[q] != l4[q] || std::memcmp(&s3[q], &s4[q], 8) != 0) { std::fprintf(stderr, "eval_graphs != eval_batch (%d)\n", q); return 1; }
+            const int32_t bad_seed[3] = {0, n, 0};
+            EXPECT_FAIL(rwr_eval_graphs(3, dd, bad_seed, 0.15f, 6, tp, test.data(), &o, h4, s4, l4), RWR_E_RANGE);
+        }
         CHECK(rwr_model_run(g, 1, 0.15, RWR_RUN_ITERATIONS, 4, rank.data(), &iters));
         CHECK(rwr_model_run(g, 1, 0.15, RWR_RUN_THRESHOLD, 1e-3, rank.data(), &iters));
         CHECK(rwr_model_run(g, -1, 0.15, RWR_RUN_ITERATIONS, 3, rank.data(), &iters));

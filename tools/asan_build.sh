@@ -7,7 +7,7 @@ set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/build/asan
 mkdir -p $out
-for f in api build iterate spmv spmv_blocked small chain_scan rank sort; do
+for f in api build iterate spmv sweep small chain_scan rank sort; do
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-gpu-flush-denormals-to-zero \
       -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer \
       -c $root/recommendersystems_amd/csrc/$f.hip -o $out/$f.o &
