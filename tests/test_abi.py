@@ -157,3 +157,16 @@ def test_csharp_shim_structs_match_the_ctypes_mirror():
         n_c = 0 if args in ("", "void") else args.count(",") + 1
         n_cs = 0 if not params.strip() else params.count(",") + 1
         assert n_c == n_cs, (name, n_c, n_cs)
+
+
+def test_native_thread_tool_builds(tmp_path):
+    """tools/eval_graphs_threads.cpp (the host-thread scaling measurement bench.py --config C1 runs as a child process) compiles
+    and links against the library with the header alone."""
+    import subprocess
+    L = _lib()
+    pkg = os.path.dirname(L.LIB_PATH)
+    exe = tmp_path / "egt"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "eval_graphs_threads.cpp"), "-o", str(exe), os.path.join(pkg, "librwr.so"),
+                           "-Wl,-rpath," + pkg])
+    assert exe.exists()
