@@ -471,12 +471,13 @@ __global__ __launch_bounds__(64) void k_cs_carry(int32_t n, int nchunks, const u
 //   * anything else -- two crossings in a block behind the first, a link into the seed inside the split run, a subnormal
 //     incoming sum -- is left to the carry's redo                                                               (CS_REDO).
 // The prediction (k_cs_plan) is folded into the block kernel: every workgroup sums the approximate block sums in front of it.
-constexpr int CS_PLAIN = 0, CS_SPLIT = 1, CS_EXACT = 2, CS_REDO = 3;
+constexpr int CS_PLAIN = 0, CS_SPLIT = 1, CS_EXACT = 2, CS_REDO = 3, CS_SPLIT2 = 4;
 #ifdef RWR_EXPERIMENTS
 __device__ int cs_carry_dbg = 0;     // RWR_X_CARRY_DBG=1: the carry prints what it did with its blocks
 #endif
 constexpr int CS_KIND_SHIFT = 12;                       // cs_e cell: predicted exponent | kind << 12
-constexpr int CS_SIDE_WORDS = 8;                        // a[0..3], after.d0, after.d1, exact, (spare)
+constexpr int CS_SIDE_WORDS = 32;                       // [0..7] first run's addends, [8,9] after (SPLIT2: the middle), [10] exact, [12..19] second run's addends, [20,21] after2
+constexpr int CS_RUN_ADDENDS = 8;                       // a crossing run hands over up to 8 addends: its 4 restart addends and the links into the seed among its rows
 typedef double v2d_t __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const uint8_t *__restrict__ dangling,
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
                     for (int k = 0; k < 16; ++k) t += v[k];
                 }
             }
-            sd[6] = t;
+            sd[10] = t;
             ek[oidx] = CS_EXACT << CS_KIND_SHIFT;
             od0[oidx] = 0;
             od1[oidx] = 0;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
     }
     const double post = pre + ap;
     const int epost = (int)(((unsigned long long)__double_as_longlong(post) >> 52) & 0x7ff);
-    if (epre == 0 || epost >= 0x7ff || epost > epre + 1) {
+    if (epre == 0 || epost >= 0x7ff || epost > epre + 2) {
 #ifdef RWR_EXPERIMENTS
         if (cs_carry_dbg && tid == 0) printf("  block %d: redo kind, pre %.17g (e %d) ap %.17g post e %d\n", c, pre, epre, ap, epost);
 #endif
@@ -625,56 +626,141 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
         return;
     }
     // split: exclusive / inclusive prefix of the runs (wave scan + the four wave totals), located against the approximate
-    // incoming mantissa
-    PF inc = f;
+    // incoming mantissa.  scan() must be called by every thread.
+    auto scan = [&](PF fr, PF &inc, PF &exc) {
+        inc = fr;
 #pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-        PF o;
-        o.d0 = __shfl_up(inc.d0, off, WAVE);
-        o.d1 = __shfl_up(inc.d1, off, WAVE);
-        if (lane >= off) inc = pf_compose(o, inc);
-    }
-    if (lane == WAVE - 1) { w0[wave] = inc.d0; w1[wave] = inc.d1; }
-    if (tid == 0) rstar = -1;
-    __syncthreads();
-    PF prew{0, 0};
-    for (int w = 0; w < wave; ++w) prew = pf_compose(prew, PF{w0[w], w1[w]});
-    PF exc;
-    exc.d0 = __shfl_up(inc.d0, 1, WAVE);
-    exc.d1 = __shfl_up(inc.d1, 1, WAVE);
-    if (lane == 0) exc = PF{0, 0};
-    exc = pf_compose(prew, exc);
-    inc = pf_compose(prew, inc);
+        for (int off = 1; off < WAVE; off <<= 1) {
+            PF o;
+            o.d0 = __shfl_up(inc.d0, off, WAVE);
+            o.d1 = __shfl_up(inc.d1, off, WAVE);
+            if (lane >= off) inc = pf_compose(o, inc);
+        }
+        __syncthreads();                                     // (the totals of an earlier scan have been read)
+        if (lane == WAVE - 1) { w0[wave] = inc.d0; w1[wave] = inc.d1; }
+        __syncthreads();
+        PF prew{0, 0};
+        for (int w = 0; w < wave; ++w) prew = pf_compose(prew, PF{w0[w], w1[w]});
+        exc.d0 = __shfl_up(inc.d0, 1, WAVE);
+        exc.d1 = __shfl_up(inc.d1, 1, WAVE);
+        if (lane == 0) exc = PF{0, 0};
+        exc = pf_compose(prew, exc);
+        inc = pf_compose(prew, inc);
+    };
+    // the run in which mantissa mt (approximate) leaves the binade: the function of the runs in front of it and the run's own
+    // addend sequence -- per row its links into the seed (list order), then its restart addend (Model.cs:85-93,96-97); the
+    // links into the seed come from the nodes that hold most of the rank, so the crossing run often has one -- come back
+    // through LDS, padded with +0.0.  -1: no such run; over: the run has more than CS_RUN_ADDENDS addends.
+    __shared__ long long xb0, xb1;
+    __shared__ double xa[CS_RUN_ADDENDS];
+    __shared__ int xover;
+    auto locate = [&](long long mt, const PF &inc, const PF &exc, PF &front, bool &over) -> int {
+        if (tid == 0) rstar = -1;
+        __syncthreads();
+        if (mt + exc.d0 < CS_BIG && mt + inc.d0 >= CS_BIG) {       // (monotone: at most one run)
+            rstar = tid;
+            xb0 = exc.d0;
+            xb1 = exc.d1;
+            int cnt = 0, ov = 0;
+            int32_t l = lb;
+            for (int u = 0; u < CS_R; ++u) {
+                if (haslink)
+                    while (l < l1 && (int64_t)srcp[l] == ra + u) {
+                        if (cnt < CS_RUN_ADDENDS) xa[cnt] = cs_term(termp, zt, srcp, l, 1);
+                        else ov = 1;
+                        ++cnt;
+                        ++l;
+                    }
+                if (cnt < CS_RUN_ADDENDS) xa[cnt] = a_s[cs_pad(tid * CS_R + u)];
+                else ov = 1;
+                ++cnt;
+            }
+            for (int q = cnt; q < CS_RUN_ADDENDS; ++q) xa[q] = 0.0;
+            xover = ov;
+        }
+        __syncthreads();
+        const int r = rstar;
+        front = PF{xb0, xb1};
+        over = r >= 0 && xover != 0;
+        return r;
+    };
+    auto redo_kind = [&](int why) {
+#ifdef RWR_EXPERIMENTS
+        if (cs_carry_dbg && tid == 0) printf("  block %d: redo kind, reason %d (1 first run too long, 2 sum behind first run not in e+1, 3 second run too long); pre %.6g ap %.6g\n", c, why, pre, ap);
+#endif
+        (void)why;
+        if (tid == 0) { ek[oidx] = epre | (CS_REDO << CS_KIND_SHIFT); od0[oidx] = 0; od1[oidx] = 0; }
+    };
+    PF inc, exc;
+    scan(f, inc, exc);
     const long long mt = (long long)(((unsigned long long)__double_as_longlong(pre) & CS_FRAC) | CS_HID);
-    if (mt + exc.d0 < CS_BIG && mt + inc.d0 >= CS_BIG) rstar = tid;      // (monotone: at most one run)
-    __syncthreads();
-    const int rs = rstar;
+    PF before;
+    bool over1 = false;
+    const int rs = locate(mt, inc, exc, before, over1);
     if (rs < 0) {
         // the approximate sums say the binade is left, the scan does not: hand over the whole block under e; the carry checks
         const PF tot = reduce(f);
         if (tid == 0) { ek[oidx] = epre | (CS_PLAIN << CS_KIND_SHIFT); od0[oidx] = tot.d0; od1[oidx] = tot.d1; }
         return;
     }
-    if (tid == rs) { w0[0] = exc.d0; w1[0] = exc.d1; w0[1] = haslink ? 1 : 0; }
-    __syncthreads();
-    const PF before{w0[0], w1[0]};
-    const bool link_in_run = w0[1] != 0;
-    __syncthreads();
-    if (link_in_run) {
-        if (tid == 0) { ek[oidx] = epre | (CS_REDO << CS_KIND_SHIFT); od0[oidx] = 0; od1[oidx] = 0; }
-        return;
-    }
+    if (over1) { redo_kind(1); return; }
+    double run1[CS_RUN_ADDENDS];
+#pragma unroll
+    for (int q = 0; q < CS_RUN_ADDENDS; ++q) run1[q] = xa[q];
     PF g{0, 0};
     if (tid > rs) g = run_pf(epre + 1);
-    const PF after = reduce(g);
+    auto emit_split = [&](const PF &after) {
+        if (tid == 0) {
+            ek[oidx] = epre | (CS_SPLIT << CS_KIND_SHIFT);
+            od0[oidx] = before.d0;
+            od1[oidx] = before.d1;
+#pragma unroll
+            for (int q = 0; q < CS_RUN_ADDENDS; ++q) sd[q] = run1[q];
+            sd[8] = __longlong_as_double(after.d0);
+            sd[9] = __longlong_as_double(after.d1);
+        }
+    };
+    if (epost == epre + 1) {
+        const PF after = reduce(g);                          // (its barriers also order the reads of xa above before any rewrite)
+        emit_split(after);
+        return;
+    }
+    // two crossings (the sum more than doubles inside the block: the ranks are still concentrated): the second run is located
+    // the same way, under e + 1, from the approximate sum behind the first run
+    double s1 = cs_from_m(epre, mt + before.d0);
+#pragma unroll
+    for (int q = 0; q < CS_RUN_ADDENDS; ++q) s1 += run1[q];
+    const unsigned long long s1b = (unsigned long long)__double_as_longlong(s1);
+    if ((int)((s1b >> 52) & 0x7ff) != epre + 1 || epre + 2 >= 0x7ff) { redo_kind(2); return; }   // (uniform: s1 is the same in every thread)
+    PF inc2, exc2;
+    scan(g, inc2, exc2);
+    const long long mt1 = (long long)((s1b & CS_FRAC) | CS_HID);
+    PF middle;
+    bool over2 = false;
+    const int rs2 = locate(mt1, inc2, exc2, middle, over2);
+    if (rs2 < 0) {
+        // no second crossing in sight after all: a single split, checked by the carry
+        const PF after = reduce(g);
+        emit_split(after);
+        return;
+    }
+    if (over2) { redo_kind(3); return; }
+    double run2[CS_RUN_ADDENDS];
+#pragma unroll
+    for (int q = 0; q < CS_RUN_ADDENDS; ++q) run2[q] = xa[q];
+    PF g2{0, 0};
+    if (tid > rs2) g2 = run_pf(epre + 2);
+    const PF after2 = reduce(g2);
     if (tid == 0) {
-        ek[oidx] = epre | (CS_SPLIT << CS_KIND_SHIFT);
+        ek[oidx] = epre | (CS_SPLIT2 << CS_KIND_SHIFT);
         od0[oidx] = before.d0;
         od1[oidx] = before.d1;
 #pragma unroll
-        for (int u = 0; u < CS_R; ++u) sd[u] = a_s[cs_pad(rs * CS_R + u)];
-        sd[4] = __longlong_as_double(after.d0);
-        sd[5] = __longlong_as_double(after.d1);
+        for (int q = 0; q < CS_RUN_ADDENDS; ++q) { sd[q] = run1[q]; sd[12 + q] = run2[q]; }
+        sd[8] = __longlong_as_double(middle.d0);
+        sd[9] = __longlong_as_double(middle.d1);
+        sd[20] = __longlong_as_double(after2.d0);
+        sd[21] = __longlong_as_double(after2.d1);
     }
 }
 
@@ -706,8 +792,9 @@ __global__ __launch_bounds__(64) void k_cs_carry1(int32_t n, int nchunks, const 
         double ap;
         int32_t ek;
         long long f0, f1;
-        v2d_t s01, s23, s45;                              // side words 0..5
-        double s6;
+        v2d_t a01, a23, a45, a67, af;                     // side words 0..9: first run's addends, the function behind it
+        double ex;                                        // word 10: exact sum (CS_EXACT)
+        v2d_t b01, b23, b45, b67, bf;                     // words 12..21: second run's addends, the function behind it (CS_SPLIT2)
     };
     auto load = [&](int C, Win &w) {
         const int cc = C + lane;
@@ -718,10 +805,9 @@ __global__ __launch_bounds__(64) void k_cs_carry1(int32_t n, int nchunks, const 
         w.f0 = d0[i];
         w.f1 = d1[i];
         const v2d_t *sp = reinterpret_cast<const v2d_t *>(side + i * CS_SIDE_WORDS);
-        w.s01 = sp[0];
-        w.s23 = sp[1];
-        w.s45 = sp[2];
-        w.s6 = side[i * CS_SIDE_WORDS + 6];
+        w.a01 = sp[0]; w.a23 = sp[1]; w.a45 = sp[2]; w.a67 = sp[3]; w.af = sp[4];
+        w.ex = side[i * CS_SIDE_WORDS + 10];
+        w.b01 = sp[6]; w.b23 = sp[7]; w.b45 = sp[8]; w.b67 = sp[9]; w.bf = sp[10];
     };
     Win cur, nxt;
     int c = 0;
@@ -762,27 +848,47 @@ __global__ __launch_bounds__(64) void k_cs_carry1(int32_t n, int nchunks, const 
         eb = (int)((b >> 52) & 0x7ff);
         normal = eb != 0 && eb != 0x7ff;
         bool handled = false;
+        // the run's addends (uniform copies of lane L's registers), added in order with real fp64 adds; padding is +0.0
+        auto add_run = [&](double t, const v2d_t &p01, const v2d_t &p23, const v2d_t &p45, const v2d_t &p67) {
+            t += __shfl(p01.x, L, WAVE); t += __shfl(p01.y, L, WAVE);
+            t += __shfl(p23.x, L, WAVE); t += __shfl(p23.y, L, WAVE);
+            t += __shfl(p45.x, L, WAVE); t += __shfl(p45.y, L, WAVE);
+            t += __shfl(p67.x, L, WAVE); t += __shfl(p67.y, L, WAVE);
+            return t;
+        };
+        auto pf_at = [&](const v2d_t &p) { return PF{__double_as_longlong(__shfl(p.x, L, WAVE)), __double_as_longlong(__shfl(p.y, L, WAVE))}; };
         if (kL == CS_EXACT && b == 0ull) {
-            s = __shfl(cur.s6, L, WAVE);
+            s = __shfl(cur.ex, L, WAVE);
             handled = true;
-        } else if (kL == CS_SPLIT && normal && eL == eb && eb + 1 < 0x7ff) {
+        } else if ((kL == CS_SPLIT || kL == CS_SPLIT2) && normal && eL == eb && eb + 2 < 0x7ff) {
+            // function, the run's real adds, function [, the second run's real adds, function] -- every part checked
             const PF before{__shfl(cur.f0, L, WAVE), __shfl(cur.f1, L, WAVE)};
             m = (long long)((b & CS_FRAC) | CS_HID);
             const long long M1 = m + ((m & 1) ? before.d1 : before.d0);
             if (M1 < CS_BIG) {                            // still inside the binade in front of the run
-                double t = cs_from_m(eb, M1);
-                t += __shfl(cur.s01.x, L, WAVE);          // the run's four rows, real adds (Model.cs:91-93,96-97)
-                t += __shfl(cur.s01.y, L, WAVE);
-                t += __shfl(cur.s23.x, L, WAVE);
-                t += __shfl(cur.s23.y, L, WAVE);
-                const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+                double t = add_run(cs_from_m(eb, M1), cur.a01, cur.a23, cur.a45, cur.a67);
+                unsigned long long tb = (unsigned long long)__double_as_longlong(t);
                 if ((int)((tb >> 52) & 0x7ff) == eb + 1) {
-                    const PF after{__double_as_longlong(__shfl(cur.s45.x, L, WAVE)), __double_as_longlong(__shfl(cur.s45.y, L, WAVE))};
+                    const PF mid = pf_at(cur.af);
                     const long long m2 = (long long)((tb & CS_FRAC) | CS_HID);
-                    const long long M2 = m2 + ((m2 & 1) ? after.d1 : after.d0);
+                    const long long M2 = m2 + ((m2 & 1) ? mid.d1 : mid.d0);
                     if (M2 < CS_BIG) {
-                        s = cs_from_m(eb + 1, M2);
-                        handled = true;
+                        if (kL == CS_SPLIT) {
+                            s = cs_from_m(eb + 1, M2);
+                            handled = true;
+                        } else {
+                            t = add_run(cs_from_m(eb + 1, M2), cur.b01, cur.b23, cur.b45, cur.b67);
+                            tb = (unsigned long long)__double_as_longlong(t);
+                            if ((int)((tb >> 52) & 0x7ff) == eb + 2) {
+                                const PF aft = pf_at(cur.bf);
+                                const long long m3 = (long long)((tb & CS_FRAC) | CS_HID);
+                                const long long M3 = m3 + ((m3 & 1) ? aft.d1 : aft.d0);
+                                if (M3 < CS_BIG) {
+                                    s = cs_from_m(eb + 2, M3);
+                                    handled = true;
+                                }
+                            }
+                        }
                     }
                 }
             }

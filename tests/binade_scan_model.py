@@ -155,3 +155,64 @@ def apply_split(s: float, sp):
     if M2 >= BIG:
         return None
     return from_bits(((eb + 1) << 52) | (M2 - (1 << 52)))
+
+
+def split_block2(pre_approx: float, block, run=4):
+    """Two crossings in one block (chain_scan.hip: CS_SPLIT2): the first crossing run located under e with the approximate
+    incoming mantissa, the second under e + 1 with the approximate sum behind the first run.  None when either is not found."""
+    first = split_block(pre_approx, block, run)
+    if first is None:
+        return None
+    eb = first["eb"]
+    mt = (bits(pre_approx) & ((1 << 52) - 1)) | (1 << 52)
+    s1 = from_bits((eb << 52) | (mt + first["before"][0] - (1 << 52)))
+    for a in first["rows"]:
+        s1 = s1 + a
+    if ((bits(s1) >> 52) & 0x7FF) != eb + 1 or eb + 2 >= 0x7FF:
+        return None
+    # the rows behind the first run, located again one binade up
+    n_front = 0
+    runs = [block[i:i + run] for i in range(0, len(block), run)]
+    for r, rows in enumerate(runs):
+        if list(rows) == first["rows"] and all(x is y or x == y for x, y in zip(rows, first["rows"])):
+            n_front = (r + 1) * run
+            break
+    rest = block[n_front:]
+    second = split_block(s1, rest, run)
+    if second is None:
+        return None
+    return {"eb": eb, "before": first["before"], "rows1": first["rows"], "middle": second["before"], "rows2": second["rows"],
+            "after": second["after"]}
+
+
+def apply_split2(s: float, sp):
+    """The carry's side for two crossings: function, real adds, function, real adds, function -- each part checked."""
+    if sp is None:
+        return None
+    b = bits(s)
+    eb = (b >> 52) & 0x7FF
+    if eb != sp["eb"]:
+        return None
+    m = (b & ((1 << 52) - 1)) | (1 << 52)
+    M1 = m + sp["before"][m & 1]
+    if M1 >= BIG:
+        return None
+    t = from_bits((eb << 52) | (M1 - (1 << 52)))
+    for a in sp["rows1"]:
+        t = t + a
+    if ((bits(t) >> 52) & 0x7FF) != eb + 1:
+        return None
+    m2 = (bits(t) & ((1 << 52) - 1)) | (1 << 52)
+    M2 = m2 + sp["middle"][m2 & 1]
+    if M2 >= BIG:
+        return None
+    t = from_bits(((eb + 1) << 52) | (M2 - (1 << 52)))
+    for a in sp["rows2"]:
+        t = t + a
+    if ((bits(t) >> 52) & 0x7FF) != eb + 2:
+        return None
+    m3 = (bits(t) & ((1 << 52) - 1)) | (1 << 52)
+    M3 = m3 + sp["after"][m3 & 1]
+    if M3 >= BIG:
+        return None
+    return from_bits(((eb + 2) << 52) | (M3 - (1 << 52)))

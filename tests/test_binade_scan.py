@@ -105,3 +105,35 @@ def test_split_blocks_are_exact_or_refused():
             accepted += 1
             assert m.bits(got) == m.bits(want), (trial, err)
     assert accepted > 150 and refused > 0
+
+
+def test_double_split_blocks_are_exact_or_refused():
+    """CS_SPLIT2: a block over which the sum crosses TWO binade boundaries (it more than doubles: the ranks are still
+    concentrated around the seed) -- located with approximate sums, applied to the exact one, every part checked."""
+    rng = random.Random(77)
+    accepted = refused = 0
+    for trial in range(300):
+        front = [rng.random() * 1e-3 for _ in range(rng.randrange(20, 200))]
+        s = seq_sum(front)
+        eb = (m.bits(s) >> 52) & 0x7FF
+        top2 = m.from_bits((eb + 2) << 52)
+        rows = rng.choice([64, 256, 1024])
+        need = (top2 - s) * (1.05 + 0.6 * rng.random())          # ends inside binade e + 2
+        block = [need / rows * (0.5 + rng.random()) for _ in range(rows)]
+        want = s
+        for a in block:
+            want = want + a
+        if ((m.bits(want) >> 52) & 0x7FF) != eb + 2:
+            continue
+        err = rng.choice([0.0, 1e-13, -1e-13, 1e-9, -1e-9, 2e-3, -2e-3, 5e-2])
+        pre = s * (1.0 + err)
+        if ((m.bits(pre) >> 52) & 0x7FF) != eb:
+            continue
+        sp = m.split_block2(pre, block, run=4)
+        got = m.apply_split2(s, sp)
+        if got is None:
+            refused += 1
+        else:
+            accepted += 1
+            assert m.bits(got) == m.bits(want), (trial, err)
+    assert accepted > 100 and refused > 0

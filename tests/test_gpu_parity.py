@@ -616,7 +616,8 @@ def test_seed_row_binade_scan_bitwise(amd, tile_seeds):
         G.close()
     nblocks = -(-n * tile_seeds // 4096)
     assert outs["fold"] == 0
-    assert 0 < outs["scan"] < 0.5 * nblocks * len(seeds) * 7, outs
+    # (a single seed's crossings are predicted in the parallel pass -- chain_scan.hip: k_cs_block1 -- and none may need a redo)
+    assert (0 if tile_seeds == 1 else 1) <= outs["scan"] < 0.5 * nblocks * len(seeds) * 7, outs
 
 
 def test_dangling_seeds_in_a_batch(amd):
