@@ -484,10 +484,13 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
                                                    const double *__restrict__ X, const int32_t *__restrict__ seeds, double c1,
                                                    const int64_t *__restrict__ in_ptr, const int32_t *__restrict__ in_src,
                                                    const int64_t *__restrict__ evoff, const double *__restrict__ evterm,
-                                                   const int32_t *__restrict__ lnk, const double *__restrict__ approx,
+                                                   const int32_t *__restrict__ lnk, double *__restrict__ approx,
                                                    int32_t *__restrict__ ek, long long *__restrict__ od0,
-                                                   long long *__restrict__ od1, double *__restrict__ side)
+                                                   long long *__restrict__ od1, double *__restrict__ side, int own_sums)
 {
+    // own_sums: graphs of a few dozen blocks (ego-network sizes) skip the separate pass of approximate block sums
+    // (k_cs_block<1,false>): every workgroup adds up the addends in front of its block itself -- at most a few tens of
+    // thousands of rows out of the L2 -- and writes its own block's sum for the carry: one launch less per step
     constexpr int CH = CsGeom<1>::CH, CS_R = CsGeom<1>::R;      // 1024 rows per block, 4 per thread
     __shared__ double a_s[CH + CH / 16];
     __shared__ long long r0[256], r1[256];
@@ -497,12 +500,34 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
     const double *x = X + (size_t)slot * (size_t)n;
     const int32_t s = seeds[slot];
     const size_t base = (size_t)slot * nchunks, oidx = base + c;
+    // this block's share of the seed's in-link list (sorted by source row)
+    int32_t l1 = 0, a0 = 0;
+    const int32_t *srcp = in_src;
+    const double *termp = evterm, *zt = nullptr;
+    if (s >= 0) {
+        const int32_t *lk = lnk + (size_t)slot * (size_t)(nchunks + 1) + c;
+        a0 = lk[0];
+        l1 = lk[1];
+        if (l1 > 0) {
+            srcp = in_src + in_ptr[s];
+            if (evoff) termp = evterm + evoff[slot]; else zt = evterm + (size_t)slot * (size_t)n;
+        }
+    }
     // the approximate sum in front of this block (any association will do for a prediction)
-    double pa = 0.0;
-    for (int i = tid; i < c; i += 256) pa += approx[base + i];
-    const double ap = approx[oidx];
-    // this block's addends, staged in LDS
     const int64_t row0 = (int64_t)c * CH;
+    double pa = 0.0, apl = 0.0;
+    if (own_sums) {
+        for (int64_t i = tid; i < row0; i += 256) {
+            const double xv = x[i];
+            const double rw = c1 * xv;
+            pa += dangling[i] ? xv : (xv - rw);
+        }
+        for (int32_t l = tid; l < a0; l += 256) pa += cs_term(termp, zt, srcp, l, 1);
+        for (int32_t l = a0 + tid; l < l1; l += 256) apl += cs_term(termp, zt, srcp, l, 1);
+    } else {
+        for (int i = tid; i < c; i += 256) pa += approx[base + i];
+    }
+    // this block's addends, staged in LDS
 #pragma unroll
     for (int j = 0; j < CH / 256; ++j) {
         const int q = tid + 256 * j;
@@ -514,34 +539,25 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
             a = dangling[row] ? xv : (xv - rw);              // Model.cs:97 / :91
         }
         a_s[cs_pad(q)] = a;
+        apl += own_sums ? a : 0.0;
     }
-    double *racc = reinterpret_cast<double *>(r0);
+    double *racc = reinterpret_cast<double *>(r0), *racc2 = reinterpret_cast<double *>(r1);
     racc[tid] = pa;
+    racc2[tid] = apl;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
-        if (tid < st) racc[tid] += racc[tid + st];
+        if (tid < st) { racc[tid] += racc[tid + st]; racc2[tid] += racc2[tid + st]; }
         __syncthreads();
     }
     const double pre = racc[0];
-    __syncthreads();                                         // (r0 is reused below)
+    const double ap = own_sums ? racc2[0] : approx[oidx];
+    __syncthreads();                                         // (r0 / r1 are reused below)
+    if (own_sums && tid == 0) approx[oidx] = ap;             // (the carry skips blocks whose sum is +0.0)
     double *sd = side + oidx * CS_SIDE_WORDS;
     const int epre = (int)(((unsigned long long)__double_as_longlong(pre) >> 52) & 0x7ff);
     if (ap == 0.0) {                                         // every addend +0.0: a no-op for the carry
         if (tid == 0) { ek[oidx] = epre | (CS_PLAIN << CS_KIND_SHIFT); od0[oidx] = 0; od1[oidx] = 0; }
         return;
-    }
-    // this block's share of the seed's in-link list (sorted by source row)
-    int32_t l1 = 0, a0 = 0;
-    const int32_t *srcp = in_src;
-    const double *termp = evterm, *zt = nullptr;
-    if (s >= 0) {
-        const int32_t *lk = lnk + (size_t)slot * (size_t)(nchunks + 1) + c;
-        a0 = lk[0];
-        l1 = lk[1];
-        if (l1 > a0) {
-            srcp = in_src + in_ptr[s];
-            if (evoff) termp = evterm + evoff[slot]; else zt = evterm + (size_t)slot * (size_t)n;
-        }
     }
     if (pre == 0.0) {
         // nothing non-zero in front: the sum enters as exactly +0.0 and one thread adds the block up in the reference's order
@@ -1039,11 +1055,14 @@ static int32_t chain_scan_launch(rwr_graph *g, int G, int tg, const double *X, d
     }
     if (self) {
         // prediction, split and exact-start blocks in one pass; the carry applies them from registers
-        hipLaunchKernelGGL((k_cs_block<1, false>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X, d_seeds, c1, g->in_ptr.p,
-                           g->in_src.p, evo, evt, lnk, (const int32_t *)nullptr, g->cs_approx.p, (long long *)nullptr,
-                           (long long *)nullptr);
+        static const int own_max = [] { const char *e = RWR_TUNE_ENV("RWR_SCAN_OWN_SUMS_BLOCKS"); return e ? atoi(e) : 48; }();
+        const int own_sums = nchunks <= own_max ? 1 : 0;
+        if (!own_sums)
+            hipLaunchKernelGGL((k_cs_block<1, false>), grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X, d_seeds, c1, g->in_ptr.p,
+                               g->in_src.p, evo, evt, lnk, (const int32_t *)nullptr, g->cs_approx.p, (long long *)nullptr,
+                               (long long *)nullptr);
         hipLaunchKernelGGL(k_cs_block1, grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X, d_seeds, c1, g->in_ptr.p, g->in_src.p,
-                           evo, evt, lnk, g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, g->cs_side.p);
+                           evo, evt, lnk, g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, g->cs_side.p, own_sums);
         hipLaunchKernelGGL(k_cs_carry1, dim3((unsigned)tg), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y, d_seeds, c1, g->in_ptr.p,
                            g->in_src.p, evo, evt, lnk, g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, g->cs_side.p, nz_out,
                            g->cs_redo.p, zout, g->w_src.p);
