@@ -13,6 +13,7 @@ constexpr size_t SMALL_SORT_MAX = 20480;
 
 // LDS the sort needs (declared by the calling kernel so that several stages can share one workgroup)
 struct SmallSortLds {
+    uint32_t single;                 // this pass's digit is the same for every key: the pass is a plain copy
     uint32_t run[SMALL_SORT_RADIX];
     uint32_t wcnt[SMALL_SORT_THREADS / WAVE][SMALL_SORT_RADIX];
     uint32_t wsum[SMALL_SORT_RADIX / WAVE];
@@ -32,6 +33,7 @@ __device__ __forceinline__ void sort_small_body(SmallSortLds &L, KeyT *ka, KeyT 
     uint32_t *vin = va, *vout = vb;
     for (int shift = 0; shift < key_bits; shift += 8) {
         if (tid < RADIX) L.run[tid] = 0;
+        if (tid == 0) L.single = 0;
         for (int i = tid; i < NW * RADIX; i += SMALL_SORT_THREADS) (&L.wcnt[0][0])[i] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < m; i += SMALL_SORT_THREADS) atomicAdd(&L.run[(unsigned)(kin[i] >> shift) & (RADIX - 1)], 1u);
@@ -40,6 +42,7 @@ __device__ __forceinline__ void sort_small_body(SmallSortLds &L, KeyT *ka, KeyT 
         uint32_t v = 0, incl = 0;
         if (tid < RADIX) {
             v = L.run[tid];
+            if (v == m) L.single = 1;          // (e.g. the sign / exponent byte of a score key: every key in one bin)
             incl = v;
 #pragma unroll
             for (int off = 1; off < WAVE; off <<= 1) {
@@ -55,6 +58,13 @@ __device__ __forceinline__ void sort_small_body(SmallSortLds &L, KeyT *ka, KeyT 
             L.run[tid] = pre + incl - v;
         }
         __syncthreads();
+        if (L.single) {                        // a stable sort on a constant digit keeps the order: copy (the buffers still alternate)
+            for (uint32_t i = tid; i < m; i += SMALL_SORT_THREADS) { kout[i] = kin[i]; vout[i] = vin[i]; }
+            __syncthreads();
+            { KeyT *t = kin; kin = kout; kout = t; }
+            { uint32_t *t = vin; vin = vout; vout = t; }
+            continue;
+        }
         // stable scatter, tile by tile in index order
         for (uint32_t base = 0; base < m; base += SMALL_SORT_THREADS) {
             const uint32_t idx = base + tid;
