@@ -1045,7 +1045,9 @@ static int32_t chain_scan_launch(rwr_graph *g, int G, int tg, const double *X, d
 #endif
     const int64_t *evo = (self && zterms) ? nullptr : d_evoff;
     const double *evt = (self && zterms) ? zterms : g->d_evterm.p;
-    if (nchunks <= direct_max) {
+    // (a single seed takes the direct walk for one block only: with the crossings predicted the two-launch form costs ~20 us per
+    //  step whatever the blocks hold, the direct walk 8-9 us per redone block -- 7 500 nodes: 1.83 -> 0.58 ms per call)
+    if (nchunks <= (self ? 1 : direct_max)) {
         CS_DISPATCH_G(G, hipLaunchKernelGGL(k_cs_carry<GG>, dim3((unsigned)(tg * G)), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y,
                                             d_seeds, c1, g->in_ptr.p, g->in_src.p, evo, evt, lnk,
                                             g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, nz_out, g->cs_redo.p, 1,

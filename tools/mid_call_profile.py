@@ -1,4 +1,5 @@
-"""One mid-size ego network (12 K nodes, 195 K links), the single-seed call repeated (for rocprofv3 --kernel-trace --stats)."""
+"""One mid-size ego network (8k / 12k / 120k nodes: beyond the one-launch path of small.hip), the single-seed call repeated
+(for rocprofv3 --kernel-trace --stats).   python tools/mid_call_profile.py 12k"""
 import os
 import sys
 import time
@@ -9,7 +10,8 @@ if os.environ.get("RWR_TOOLS_EXP_LIB"):        # the experiments build (make -C 
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "librwr_exp.so")
 from recommendersystems_amd.rwr_based import Graph, Recommender           # noqa: E402
 
-U, I, E = (2000, 10000, 100000) if len(sys.argv) < 2 or sys.argv[1] == "12k" else (20000, 100000, 1000000)
+SIZES = {"8k": (1500, 6000, 60000), "12k": (2000, 10000, 100000), "120k": (20000, 100000, 1000000)}
+U, I, E = SIZES[sys.argv[1] if len(sys.argv) > 1 else "12k"]
 g = synth.bipartite(9, U, I, E)
 flat = {k: g[k] for k in ("node_id", "node_type", "rowptr", "dst", "etype", "w")}
 G = Graph.from_flat(**flat)
