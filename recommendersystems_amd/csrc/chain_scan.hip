@@ -477,7 +477,8 @@ __device__ int cs_carry_dbg = 0;     // RWR_X_CARRY_DBG=1: the carry prints what
 #endif
 constexpr int CS_KIND_SHIFT = 12;                       // cs_e cell: predicted exponent | kind << 12
 constexpr int CS_SIDE_WORDS = 32;                       // [0..7] first run's addends, [8,9] after (SPLIT2: the middle), [10] exact, [12..19] second run's addends, [20,21] after2
-constexpr int CS_RUN_ADDENDS = 8;                       // a crossing run hands over up to 8 addends: its 4 restart addends and the links into the seed among its rows
+constexpr int CS_MX_LINKS = 8192;                       // links into the seed per 1024-row block that the exact-start block lays out in its scratch row
+constexpr int CS_RUN_ADDENDS = 8;                       // a crossing ROW hands over up to 8 addends: its links into the seed (list order) and its restart addend
 typedef double v2d_t __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const uint8_t *__restrict__ dangling,
@@ -486,7 +487,8 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
                                                    const int64_t *__restrict__ evoff, const double *__restrict__ evterm,
                                                    const int32_t *__restrict__ lnk, double *__restrict__ approx,
                                                    int32_t *__restrict__ ek, long long *__restrict__ od0,
-                                                   long long *__restrict__ od1, double *__restrict__ side, int own_sums)
+                                                   long long *__restrict__ od1, double *__restrict__ side, int own_sums,
+                                                   double *__restrict__ mx)
 {
     // own_sums: graphs of a few dozen blocks (ego-network sizes) skip the separate pass of approximate block sums
     // (k_cs_block<1,false>): every workgroup adds up the addends in front of its block itself -- at most a few tens of
@@ -549,6 +551,9 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
         if (tid < st) { racc[tid] += racc[tid + st]; racc2[tid] += racc2[tid + st]; }
         __syncthreads();
     }
+#ifdef RWR_EXPERIMENTS
+    const unsigned long long tq0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const double pre = racc[0];
     const double ap = own_sums ? racc2[0] : approx[oidx];
     __syncthreads();                                         // (r0 / r1 are reused below)
@@ -560,29 +565,83 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
         return;
     }
     if (pre == 0.0) {
-        // nothing non-zero in front: the sum enters as exactly +0.0 and one thread adds the block up in the reference's order
-        if (tid == 0) {
+        // nothing non-zero in front: the sum enters as exactly +0.0 and one thread adds the block up in the reference's order.
+        // The block's links into the seed -- an ego has in-links from most of its network: up to one per row -- are fetched by
+        // all threads first (row within the block, addend) and parked in LDS: chased through global memory by the one adding
+        // thread, each link cost two dependent round trips (~3 us: 60 us per step for 20 links, milliseconds for an ego).
+        // The block's addend sequence M -- per row its links into the seed (list order), then its restart addend -- is laid out in
+        // parallel in a global scratch row (link q of source row r_q: behind the r_q restart addends of the rows in front of
+        // its row and the q links in front of it; row r's restart addend: behind r rows and the links of the rows up to and
+        // including r), then ONE WAVE folds it: coalesced loads a line ahead, the adds strictly in order through an LDS line.
+        __shared__ double pbx[2][WAVE];
+        const int32_t nl = l1 - a0;
+        const bool staged = nl <= CS_MX_LINKS;
+        double *Mg = mx + (size_t)slot * (size_t)(CH + CS_MX_LINKS);
+        if (staged) {
+            for (int32_t q = tid; q < nl; q += 256) {
+                const int r = (int)((int64_t)srcp[a0 + q] - row0);
+                Mg[r + q] = cs_term(termp, zt, srcp, a0 + q, 1);
+            }
+#pragma unroll
+            for (int j = 0; j < CH / 256; ++j) {
+                const int r = tid + 256 * j;
+                int32_t lo = a0, hi = l1;
+                while (lo < hi) {
+                    const int32_t mid = lo + ((hi - lo) >> 1);
+                    if ((int64_t)srcp[mid] <= row0 + r) lo = mid + 1; else hi = mid;
+                }
+                Mg[r + (lo - a0)] = a_s[cs_pad(r)];
+            }
+            __threadfence_block();
+        }
+        __syncthreads();
+        if (wave == 0) {
             double t = 0.0;
-            int32_t l = a0;
-            for (int u0 = 0; u0 < CH; u0 += 16) {          // 16 rows per batch: one LDS round trip, then the dependent adds
-                double v[16];
+            if (staged) {
+                const int mlen = CH + nl;
+                int buf = 0;
+                // (four lines of 64 addends in flight: a line's 64 dependent adds take ~0.4 us, a global round trip more)
+                double pre4[4];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] = a_s[cs_pad(u0 + k)];
-                if (l < l1 && (int64_t)srcp[l] < row0 + u0 + 16) {
+                for (int d = 0; d < 4; ++d) pre4[d] = d * WAVE + lane < mlen ? Mg[d * WAVE + lane] : 0.0;
+                for (int i0 = 0; i0 < mlen; i0 += 4 * WAVE) {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        while (l < l1 && (int64_t)srcp[l] == row0 + u0 + k) { t += cs_term(termp, zt, srcp, l, 1); ++l; }   // Model.cs:85-88
-                        t += v[k];                                                                     // Model.cs:91-93,96-97
+                    for (int d = 0; d < 4; ++d) {
+                        const int at = i0 + d * WAVE;
+                        if (at >= mlen) break;                                   // (wave-uniform)
+                        const double cur = pre4[d];
+                        const int nx = at + 4 * WAVE + lane;
+                        pre4[d] = nx < mlen ? Mg[nx] : 0.0;
+                        pbx[buf][lane] = cur;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        if (mlen - at >= WAVE) {
+#pragma unroll
+                            for (int q = 0; q < WAVE; ++q) t += pbx[buf][q];     // Model.cs:85-93,96-97, in the reference's order
+                        } else {
+                            const int left = mlen - at;
+                            for (int q = 0; q < left; ++q) t += pbx[buf][q];
+                        }
+                        buf ^= 1;
                     }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) t += v[k];
+                }
+            } else if (lane == 0) {
+                // (more than CS_MX_LINKS links into the seed from one block of 1024 rows: walked through global memory)
+                int32_t l = a0;
+                for (int u = 0; u < CH; ++u) {
+                    while (l < l1 && (int64_t)srcp[l] == row0 + u) { t += cs_term(termp, zt, srcp, l, 1); ++l; }
+                    t += a_s[cs_pad(u)];
                 }
             }
+          if (lane == 0) {
+#ifdef RWR_EXPERIMENTS
+            if (cs_carry_dbg == 3) printf("  block1 c=%d exact-start: %d links staged=%d, sequential part %.1f us\n", c, nl, (int)staged, (double)(__builtin_amdgcn_s_memrealtime() - tq0) * 0.01);
+#endif
             sd[10] = t;
             ek[oidx] = CS_EXACT << CS_KIND_SHIFT;
             od0[oidx] = 0;
             od1[oidx] = 0;
+          }
         }
         return;
     }
@@ -607,17 +666,22 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
         lb = lo;
     }
     const bool haslink = lb < l1 && (int64_t)srcp[lb] < ra + CS_R;
-    auto run_pf = [&](int eb) {
+    // the rows u >= ufrom of this thread's run as one function under binade eb (ufrom > 0: the rows behind a crossing row)
+    auto run_pf_from = [&](int eb, int ufrom) {
         PF f{0, 0};
         int32_t l = lb;
 #pragma unroll
         for (int u = 0; u < CS_R; ++u) {
             if (haslink)
-                while (l < l1 && (int64_t)srcp[l] == ra + u) { f = pf_compose(f, pf_of(cs_term(termp, zt, srcp, l, 1), eb)); ++l; }   // Model.cs:85-88
-            f = pf_compose(f, pf_of(a_s[cs_pad(tid * CS_R + u)], eb));                                         // Model.cs:91-93,96-97
+                while (l < l1 && (int64_t)srcp[l] == ra + u) {                                                  // Model.cs:85-88
+                    if (u >= ufrom) f = pf_compose(f, pf_of(cs_term(termp, zt, srcp, l, 1), eb));
+                    ++l;
+                }
+            if (u >= ufrom) f = pf_compose(f, pf_of(a_s[cs_pad(tid * CS_R + u)], eb));                         // Model.cs:91-93,96-97
         }
         return f;
     };
+    auto run_pf = [&](int eb) { return run_pf_from(eb, 0); };
     // ordered tree over the 256 runs; `keep` masks a run to the identity
     auto reduce = [&](PF f) {
         r0[tid] = f.d0;
@@ -636,6 +700,9 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
         return r;
     };
     const PF f = run_pf(epre);
+#ifdef RWR_EXPERIMENTS
+    if (cs_carry_dbg == 3 && tid == 0) printf("  block1 c=%d: links %d, lower bound + run function of thread 0: %.1f us\n", c, l1 - a0, (double)(__builtin_amdgcn_s_memrealtime() - tq0) * 0.01);
+#endif
     if (epost == epre) {
         const PF tot = reduce(f);
         if (tid == 0) { ek[oidx] = epre | (CS_PLAIN << CS_KIND_SHIFT); od0[oidx] = tot.d0; od1[oidx] = tot.d1; }
@@ -663,46 +730,67 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
         exc = pf_compose(prew, exc);
         inc = pf_compose(prew, inc);
     };
-    // the run in which mantissa mt (approximate) leaves the binade: the function of the runs in front of it and the run's own
-    // addend sequence -- per row its links into the seed (list order), then its restart addend (Model.cs:85-93,96-97); the
-    // links into the seed come from the nodes that hold most of the rank, so the crossing run often has one -- come back
-    // through LDS, padded with +0.0.  -1: no such run; over: the run has more than CS_RUN_ADDENDS addends.
+    // the ROW in which mantissa mt (approximate) leaves binade eb: first the run (the scan's inclusive / exclusive functions),
+    // then, by the thread that owns it, the row inside the run.  Through LDS come back: the function of everything in front of
+    // that row, the row's own addend sequence -- its links into the seed in list order, then its restart addend
+    // (Model.cs:85-93,96-97; the seed's in-links come from the nodes that hold most of the rank, so the crossing row is more
+    // often than not one with such a link, and an ego has several links from one node), padded with +0.0 -- and the row's
+    // place in the run.  ufrom: rows of this thread's run that are already behind an earlier crossing.  -1: no such run;
+    // over: the row has more than CS_RUN_ADDENDS addends.
     __shared__ long long xb0, xb1;
     __shared__ double xa[CS_RUN_ADDENDS];
-    __shared__ int xover;
-    auto locate = [&](long long mt, const PF &inc, const PF &exc, PF &front, bool &over) -> int {
+    __shared__ int xover, xcrow;
+    auto locate = [&](long long mt, const PF &inc, const PF &exc, int eb, int ufrom, PF &front, bool &over, int &crow) -> int {
         if (tid == 0) rstar = -1;
         __syncthreads();
         if (mt + exc.d0 < CS_BIG && mt + inc.d0 >= CS_BIG) {       // (monotone: at most one run)
             rstar = tid;
-            xb0 = exc.d0;
-            xb1 = exc.d1;
-            int cnt = 0, ov = 0;
+            PF running = exc;
             int32_t l = lb;
+            int found = -1;
             for (int u = 0; u < CS_R; ++u) {
+                if (u < ufrom) {
+                    if (haslink) while (l < l1 && (int64_t)srcp[l] == ra + u) ++l;
+                    continue;
+                }
+                PF rowpf{0, 0};
+                double seq[CS_RUN_ADDENDS];
+                int cnt = 0;
                 if (haslink)
                     while (l < l1 && (int64_t)srcp[l] == ra + u) {
-                        if (cnt < CS_RUN_ADDENDS) xa[cnt] = cs_term(termp, zt, srcp, l, 1);
-                        else ov = 1;
+                        const double t = cs_term(termp, zt, srcp, l, 1);
+                        if (cnt < CS_RUN_ADDENDS) seq[cnt] = t;
                         ++cnt;
+                        rowpf = pf_compose(rowpf, pf_of(t, eb));
                         ++l;
                     }
-                if (cnt < CS_RUN_ADDENDS) xa[cnt] = a_s[cs_pad(tid * CS_R + u)];
-                else ov = 1;
+                const double a = a_s[cs_pad(tid * CS_R + u)];
+                if (cnt < CS_RUN_ADDENDS) seq[cnt] = a;
                 ++cnt;
+                rowpf = pf_compose(rowpf, pf_of(a, eb));
+                const PF incu = pf_compose(running, rowpf);
+                if (found < 0 && mt + running.d0 < CS_BIG && mt + incu.d0 >= CS_BIG) {
+                    found = u;
+                    xb0 = running.d0;
+                    xb1 = running.d1;
+                    for (int q = 0; q < CS_RUN_ADDENDS; ++q) xa[q] = q < cnt ? seq[q] : 0.0;
+                    xover = cnt > CS_RUN_ADDENDS ? 1 : 0;
+                }
+                running = incu;
             }
-            for (int q = cnt; q < CS_RUN_ADDENDS; ++q) xa[q] = 0.0;
-            xover = ov;
+            if (found < 0) { found = 0; xover = 1; }               // (cannot happen: the run-level test said the crossing is here)
+            xcrow = found;
         }
         __syncthreads();
         const int r = rstar;
         front = PF{xb0, xb1};
         over = r >= 0 && xover != 0;
+        crow = xcrow;
         return r;
     };
     auto redo_kind = [&](int why) {
 #ifdef RWR_EXPERIMENTS
-        if (cs_carry_dbg && tid == 0) printf("  block %d: redo kind, reason %d (1 first run too long, 2 sum behind first run not in e+1, 3 second run too long); pre %.6g ap %.6g\n", c, why, pre, ap);
+        if (cs_carry_dbg && tid == 0) printf("  block %d: redo kind, reason %d (1 first crossing row has too many addends, 2 sum behind it not in e+1, 3 second crossing row has too many); pre %.6g ap %.6g\n", c, why, pre, ap);
 #endif
         (void)why;
         if (tid == 0) { ek[oidx] = epre | (CS_REDO << CS_KIND_SHIFT); od0[oidx] = 0; od1[oidx] = 0; }
@@ -712,7 +800,8 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
     const long long mt = (long long)(((unsigned long long)__double_as_longlong(pre) & CS_FRAC) | CS_HID);
     PF before;
     bool over1 = false;
-    const int rs = locate(mt, inc, exc, before, over1);
+    int crow1 = 0;
+    const int rs = locate(mt, inc, exc, epre, 0, before, over1, crow1);
     if (rs < 0) {
         // the approximate sums say the binade is left, the scan does not: hand over the whole block under e; the carry checks
         const PF tot = reduce(f);
@@ -725,6 +814,7 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
     for (int q = 0; q < CS_RUN_ADDENDS; ++q) run1[q] = xa[q];
     PF g{0, 0};
     if (tid > rs) g = run_pf(epre + 1);
+    else if (tid == rs) g = run_pf_from(epre + 1, crow1 + 1);    // (the rows of the crossing run behind the crossing row)
     auto emit_split = [&](const PF &after) {
         if (tid == 0) {
             ek[oidx] = epre | (CS_SPLIT << CS_KIND_SHIFT);
@@ -753,7 +843,8 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
     const long long mt1 = (long long)((s1b & CS_FRAC) | CS_HID);
     PF middle;
     bool over2 = false;
-    const int rs2 = locate(mt1, inc2, exc2, middle, over2);
+    int crow2 = 0;
+    const int rs2 = locate(mt1, inc2, exc2, epre + 1, tid == rs ? crow1 + 1 : 0, middle, over2, crow2);
     if (rs2 < 0) {
         // no second crossing in sight after all: a single split, checked by the carry
         const PF after = reduce(g);
@@ -766,6 +857,7 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
     for (int q = 0; q < CS_RUN_ADDENDS; ++q) run2[q] = xa[q];
     PF g2{0, 0};
     if (tid > rs2) g2 = run_pf(epre + 2);
+    else if (tid == rs2) g2 = run_pf_from(epre + 2, crow2 + 1);
     const PF after2 = reduce(g2);
     if (tid == 0) {
         ek[oidx] = epre | (CS_SPLIT2 << CS_KIND_SHIFT);
@@ -969,6 +1061,7 @@ int32_t chain_scan_prepare(rwr_graph *g, int G, int tg, const int32_t *d_seeds, 
     RWR_TRY(g->cs_d0.ensure(cells));
     RWR_TRY(g->cs_d1.ensure(cells));
     if (G == 1) RWR_TRY(g->cs_side.ensure(cells * CS_SIDE_WORDS));
+    if (G == 1) RWR_TRY(g->cs_mx.ensure((size_t)tg * (size_t)(CsGeom<1>::CH + CS_MX_LINKS)));
     RWR_TRY(g->cs_lnk.ensure((size_t)tg * G * (size_t)(nchunks + 1)));
     if (!g->cs_redo.p) {
         RWR_TRY(g->cs_redo.alloc(1));
@@ -1013,6 +1106,7 @@ int32_t chain_scan_sum(rwr_graph *g, const double *D, double *out, hipStream_t s
     RWR_TRY(g->cs_d0.ensure(cells));
     RWR_TRY(g->cs_d1.ensure(cells));
     RWR_TRY(g->cs_side.ensure(cells * CS_SIDE_WORDS));
+    RWR_TRY(g->cs_mx.ensure((size_t)(CsGeom<1>::CH + CS_MX_LINKS)));
     RWR_TRY(g->cs_lnk0.ensure((size_t)nchunks + 2));
     if (!g->cs_redo.p) {
         RWR_TRY(g->cs_redo.alloc(1));
@@ -1064,7 +1158,7 @@ static int32_t chain_scan_launch(rwr_graph *g, int G, int tg, const double *X, d
                                g->in_src.p, evo, evt, lnk, (const int32_t *)nullptr, g->cs_approx.p, (long long *)nullptr,
                                (long long *)nullptr);
         hipLaunchKernelGGL(k_cs_block1, grid, dim3(256), 0, s, g->n, nchunks, g->dangling.p, X, d_seeds, c1, g->in_ptr.p, g->in_src.p,
-                           evo, evt, lnk, g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, g->cs_side.p, own_sums);
+                           evo, evt, lnk, g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, g->cs_side.p, own_sums, g->cs_mx.p);
         hipLaunchKernelGGL(k_cs_carry1, dim3((unsigned)tg), dim3(64), 0, s, g->n, nchunks, g->dangling.p, X, Y, d_seeds, c1, g->in_ptr.p,
                            g->in_src.p, evo, evt, lnk, g->cs_approx.p, g->cs_e.p, g->cs_d0.p, g->cs_d1.p, g->cs_side.p, nz_out,
                            g->cs_redo.p, zout, g->w_src.p);

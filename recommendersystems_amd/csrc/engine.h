@@ -101,7 +101,8 @@ struct rwr_graph {
     rwr::DevBuf<double> cs_approx;
     rwr::DevBuf<int32_t> cs_e;
     rwr::DevBuf<long long> cs_d0, cs_d1;
-    rwr::DevBuf<double> cs_side;      // single seed: 8 words per block (chain_scan.hip: CsSide)
+    rwr::DevBuf<double> cs_side;      // single seed: CS_SIDE_WORDS words per block (chain_scan.hip)
+    rwr::DevBuf<double> cs_mx;        // single seed: scratch row of the exact-start block's addend sequence
     rwr::DevBuf<int32_t> cs_lnk;
     rwr::DevBuf<int32_t> cs_lnk0;     // all-zero link table + slot for chain_scan_sum (checkConvergence)
     rwr::DevBuf<double> cs_diff;      // |rank - nextRank| per node (checkConvergence)

@@ -317,9 +317,11 @@ int64_t small_pin_words() { return SM_MAX_ITEMS; }
 bool small_path_ok(const rwr_graph *g)
 {
     static const int env = [] { const char *e = getenv("RWR_SMALL"); return e ? atoi(e) : 1; }();
-    // one workgroup walks every link once per step: beyond ~10^5 links the general path's whole-chip kernels are ahead
-    // (measured: 4 000 nodes / 55 K links 0.77 vs 1.37 ms, 5 500 nodes / 114 K links 1.36 vs 1.40 ms)
-    return env && g->n <= SM_MAX_N && g->n_items <= SM_MAX_ITEMS && g->n_items > 0 && g->nonneg && g->nnz <= 100000;
+    // one workgroup walks every link once per step: beyond ~65 K links the general path's whole-chip kernels are ahead
+    // (measured, round 3: 4 000 nodes / 52 K links 0.54 vs 0.61 ms, 4 700 nodes / 76 K links 0.80 vs 0.66 ms, 5 500 nodes / 92 K links
+    //  0.95 vs 0.60 ms; round 2, before the general path's chain was rebuilt: 55 K links 0.77 vs 1.37 ms) -- which is also the
+    // largest graph the one-launch build takes (build.hip: STAGE_MAX_M)
+    return env && g->n <= SM_MAX_N && g->n_items <= SM_MAX_ITEMS && g->n_items > 0 && g->nonneg && g->nnz <= 65536;
 }
 
 // One single-seed Recommendation as one launch.  The ranked list is left in d_out_id / d_out_score (row 0) on the device

@@ -386,9 +386,13 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
         (void)hipStreamWaitEvent(g->stream3, g->ev_h0, 0);
         forked = true;
     };
+    // (graphs of ego-network size: the hub kernel runs a few microseconds; a side stream would cost two cross-stream hand-overs
+    //  -- ~35 us per step measured on an 8 K-node ego network -- to overlap it with a 6 us binned kernel: it stays in line)
+    const bool hubs_in_line = !sweep && g->n < 100000;
     auto launch_hubs = [&](const int32_t *order, int32_t ra, int32_t nh) {
         if (nh <= 0) return;
-        fork();
+        hipStream_t sh = hubs_in_line ? s : g->stream3;
+        if (!hubs_in_line) fork();
         const unsigned grid = (unsigned)(nh < 4096 ? nh : 4096);
         static const int prefix = [] { const char *e = RWR_TUNE_ENV("RWR_HUB_PREFIX"); return e ? atoi(e) : 256; }();
         // beside the sweep kernel: ask for 36 KB of (unused) LDS per workgroup, more than a CU has left beside a sweep
@@ -396,10 +400,10 @@ void launch_spmv_exact(rwr_graph *g, const double *X, double *Y, const int32_t *
         static const int hub_lds_env = [] { const char *e = RWR_TUNE_ENV("RWR_HUB_LDS"); return e ? atoi(e) : 36864; }();
         const size_t hub_lds = (sweep && !g->sw_partial) ? (size_t)hub_lds_env : 0;   // (partial: the sweep holds every CU)
         if (vf)
-            hipLaunchKernelGGL(k_spmv_exact_hub<true>, dim3(grid), dim3(WAVE), hub_lds, g->stream3, ra, ra + nh, g->in_ptr.p, g->in_src.p,
+            hipLaunchKernelGGL(k_spmv_exact_hub<true>, dim3(grid), dim3(WAVE), hub_lds, sh, ra, ra + nh, g->in_ptr.p, g->in_src.p,
                                g->in_w.p, order, gs, Y, seeds, c1, skip, g->w_src.p, zout, prefix, act, nz_out);
         else
-            hipLaunchKernelGGL(k_spmv_exact_hub<false>, dim3(grid), dim3(WAVE), hub_lds, g->stream3, ra, ra + nh, g->in_ptr.p, g->in_src.p,
+            hipLaunchKernelGGL(k_spmv_exact_hub<false>, dim3(grid), dim3(WAVE), hub_lds, sh, ra, ra + nh, g->in_ptr.p, g->in_src.p,
                                g->in_w.p, order, gs, Y, seeds, c1, skip, g->w_src.p, zout, prefix, act, nz_out);
     };
     auto blocks_for = [](int64_t rows, int W) { const int64_t b = (rows * W + 255) / 256; return (int)(b < 0 ? 0 : (b > 16384 ? 16384 : b)); };

@@ -479,6 +479,54 @@ def test_eval_graphs_from_concurrent_host_threads(amd):
         assert (h == h2).all() and (sp.view(np.uint64) == sp2.view(np.uint64)).all() and (ln == ln2).all()
 
 
+@pytest.mark.parametrize("n_users,n_items", [(3000, 5200), (900, 9000)])
+def test_ego_network_beyond_the_one_launch_call(amd, n_users, n_items):
+    """An ego network too large for small.hip (more than 6144 nodes or 4096 items) through the general single-seed path: the
+    ego (node 0, the seed) has SEVERAL in-links from most of its network (FRIENDSHIP + FOLLOW + weighted MENTION from the
+    same node, as the loader builds them: DataLoader.cs:256-436), so every block of the seed-row chain is full of links into
+    the seed -- the exact-start block, the crossing rows and the redone blocks all walk them.  Bitwise against the oracle,
+    list and scores, over several iteration counts; only a handful of chain blocks may need the exact redo."""
+    rng = np.random.default_rng(n_users)
+    n = n_users + n_items
+    lists = [[] for _ in range(n)]          # (target, type, weight)
+    for u in range(1, n_users):
+        if rng.random() < 0.85:
+            lists[u].append((0, gg.EDGE_FRIENDSHIP, 1.0))
+            lists[0].append((u, gg.EDGE_FRIENDSHIP, 1.0))
+        if rng.random() < 0.7:
+            lists[u].append((0, gg.EDGE_FOLLOW, 1.0))
+        if rng.random() < 0.5:
+            lists[u].append((0, gg.EDGE_MENTION, float(rng.integers(1, 9))))
+        for v in rng.integers(1, n_users, 3):
+            if int(v) != u:
+                lists[u].append((int(v), gg.EDGE_FOLLOW, 1.0))
+    for u in range(n_users):
+        for it in rng.integers(0, n_items, 80 if u == 0 else int(rng.integers(2, 25))):
+            lists[u].append((n_users + int(it), gg.EDGE_LIKE, 1.0))
+            lists[n_users + int(it)].append((u, gg.EDGE_LIKE, 1.0))
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    for i in range(n):
+        rowptr[i + 1] = rowptr[i] + len(lists[i])
+    flat = [x for ls in lists for x in ls]
+    g = dict(node_id=rng.permutation(np.arange(10, 10 + 3 * n, 3, dtype=np.int64)),
+             node_type=np.array([gg.NODE_USER] * n_users + [gg.NODE_ITEM] * n_items, dtype=np.uint8), rowptr=rowptr,
+             dst=np.array([x[0] for x in flat], dtype=np.int32), etype=np.array([x[1] for x in flat], dtype=np.uint8),
+             w=np.array([x[2] for x in flat], dtype=np.float64))
+    F = FlatGraph(**g)
+    G = dev_graph(amd, g, profile=True)
+    rec = amd.Recommender(G)
+    for T in (1, 2, 5, 10):
+        got = rec.Recommendation(0, 0.15, T)
+        ids, sc = F.recommend(0, 0.15, T)
+        assert [r[0] for r in got] == ids.tolist(), T
+        assert (bits([r[1] for r in got]) == bits(sc)).all(), T
+    st = G.stats()
+    assert st["chain_redo_blocks"] <= 12, st["chain_redo_blocks"]          # (18 steps, 8-10 blocks each)
+    hits, sp, ln = rec.RecommendationEval(0, 0.15, 10, set(int(x) for x in ids[:30:3]))
+    assert (hits, ln) == (10, len(ids))
+    G.close()
+
+
 def test_cpp_host_mirror_runs_the_kats():
     """include/recommenders/rwr_based.hpp + tests/cpp/experiment_like.cpp: the caller pattern of
     Experiment.cs:104-128 in C++ against librwr (built by __graft_entry__.build())."""
