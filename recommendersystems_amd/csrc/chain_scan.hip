@@ -481,7 +481,7 @@ constexpr int CS_MX_LINKS = 8192;                       // links into the seed p
 constexpr int CS_RUN_ADDENDS = 8;                       // a crossing ROW hands over up to 8 addends: its links into the seed (list order) and its restart addend
 typedef double v2d_t __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const uint8_t *__restrict__ dangling,
+__global__ __launch_bounds__(256, 6) void k_cs_block1(int32_t n, int nchunks, const uint8_t *__restrict__ dangling,
                                                    const double *__restrict__ X, const int32_t *__restrict__ seeds, double c1,
                                                    const int64_t *__restrict__ in_ptr, const int32_t *__restrict__ in_src,
                                                    const int64_t *__restrict__ evoff, const double *__restrict__ evterm,
@@ -575,6 +575,42 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
         // including r), then ONE WAVE folds it: coalesced loads a line ahead, the adds strictly in order through an LDS line.
         __shared__ double pbx[2][WAVE];
         const int32_t nl = l1 - a0;
+        // (a block with a handful of links -- any seed that is not an ego -- is added up by one thread straight from LDS: no
+        //  global round trips at all, 8 us; the links wait in a small LDS table)
+        constexpr int FEW = 64;
+        __shared__ double few_term[FEW];
+        __shared__ unsigned short few_row[FEW];
+        if (nl <= FEW) {
+            for (int32_t q = tid; q < nl; q += 256) {
+                few_row[q] = (unsigned short)((int64_t)srcp[a0 + q] - row0);
+                few_term[q] = cs_term(termp, zt, srcp, a0 + q, 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+                int32_t l = 0;
+                for (int u0 = 0; u0 < CH; u0 += 16) {          // 16 rows per batch: one LDS round trip, then the dependent adds
+                    double v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = a_s[cs_pad(u0 + k)];
+                    if (l < nl && (int)few_row[l] < u0 + 16) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            while (l < nl && (int)few_row[l] == u0 + k) { t += few_term[l]; ++l; }     // Model.cs:85-88
+                            t += v[k];                                                                 // Model.cs:91-93,96-97
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) t += v[k];
+                    }
+                }
+                sd[10] = t;
+                ek[oidx] = CS_EXACT << CS_KIND_SHIFT;
+                od0[oidx] = 0;
+                od1[oidx] = 0;
+            }
+            return;
+        }
         const bool staged = nl <= CS_MX_LINKS;
         double *Mg = mx + (size_t)slot * (size_t)(CH + CS_MX_LINKS);
         if (staged) {
@@ -616,7 +652,7 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         if (mlen - at >= WAVE) {
-#pragma unroll
+#pragma unroll 16                                                                  // (16 LDS reads in flight: more would cost the whole kernel registers)
                             for (int q = 0; q < WAVE; ++q) t += pbx[buf][q];     // Model.cs:85-93,96-97, in the reference's order
                         } else {
                             const int left = mlen - at;
@@ -681,7 +717,17 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
         }
         return f;
     };
-    auto run_pf = [&](int eb) { return run_pf_from(eb, 0); };
+    auto run_pf = [&](int eb) {
+        PF f{0, 0};
+        int32_t l = lb;
+#pragma unroll
+        for (int u = 0; u < CS_R; ++u) {
+            if (haslink)
+                while (l < l1 && (int64_t)srcp[l] == ra + u) { f = pf_compose(f, pf_of(cs_term(termp, zt, srcp, l, 1), eb)); ++l; }   // Model.cs:85-88
+            f = pf_compose(f, pf_of(a_s[cs_pad(tid * CS_R + u)], eb));                                         // Model.cs:91-93,96-97
+        }
+        return f;
+    };
     // ordered tree over the 256 runs; `keep` masks a run to the identity
     auto reduce = [&](PF f) {
         r0[tid] = f.d0;
@@ -745,38 +791,40 @@ __global__ __launch_bounds__(256) void k_cs_block1(int32_t n, int nchunks, const
         __syncthreads();
         if (mt + exc.d0 < CS_BIG && mt + inc.d0 >= CS_BIG) {       // (monotone: at most one run)
             rstar = tid;
+            // pass 1: which row (functions only); pass 2: that row's addends straight into LDS (no private arrays: a dynamically
+            // indexed one would put the whole kernel on scratch memory)
             PF running = exc;
-            int32_t l = lb;
+            int32_t l = lb, lrow = lb;
             int found = -1;
-            for (int u = 0; u < CS_R; ++u) {
-                if (u < ufrom) {
-                    if (haslink) while (l < l1 && (int64_t)srcp[l] == ra + u) ++l;
-                    continue;
-                }
+            for (int u = 0; u < CS_R && found < 0; ++u) {
+                const int32_t lu = l;
                 PF rowpf{0, 0};
-                double seq[CS_RUN_ADDENDS];
-                int cnt = 0;
                 if (haslink)
                     while (l < l1 && (int64_t)srcp[l] == ra + u) {
-                        const double t = cs_term(termp, zt, srcp, l, 1);
-                        if (cnt < CS_RUN_ADDENDS) seq[cnt] = t;
-                        ++cnt;
-                        rowpf = pf_compose(rowpf, pf_of(t, eb));
+                        if (u >= ufrom) rowpf = pf_compose(rowpf, pf_of(cs_term(termp, zt, srcp, l, 1), eb));
                         ++l;
                     }
-                const double a = a_s[cs_pad(tid * CS_R + u)];
-                if (cnt < CS_RUN_ADDENDS) seq[cnt] = a;
-                ++cnt;
-                rowpf = pf_compose(rowpf, pf_of(a, eb));
+                if (u < ufrom) continue;
+                rowpf = pf_compose(rowpf, pf_of(a_s[cs_pad(tid * CS_R + u)], eb));
                 const PF incu = pf_compose(running, rowpf);
-                if (found < 0 && mt + running.d0 < CS_BIG && mt + incu.d0 >= CS_BIG) {
+                if (mt + running.d0 < CS_BIG && mt + incu.d0 >= CS_BIG) {
                     found = u;
+                    lrow = lu;
                     xb0 = running.d0;
                     xb1 = running.d1;
-                    for (int q = 0; q < CS_RUN_ADDENDS; ++q) xa[q] = q < cnt ? seq[q] : 0.0;
-                    xover = cnt > CS_RUN_ADDENDS ? 1 : 0;
                 }
                 running = incu;
+            }
+            if (found >= 0) {
+                int cnt = 0;
+                for (int32_t q = lrow; haslink && q < l1 && (int64_t)srcp[q] == ra + found; ++q) {
+                    if (cnt < CS_RUN_ADDENDS) xa[cnt] = cs_term(termp, zt, srcp, q, 1);
+                    ++cnt;
+                }
+                if (cnt < CS_RUN_ADDENDS) xa[cnt] = a_s[cs_pad(tid * CS_R + found)];
+                ++cnt;
+                for (int q = cnt; q < CS_RUN_ADDENDS; ++q) xa[q] = 0.0;
+                xover = cnt > CS_RUN_ADDENDS ? 1 : 0;
             }
             if (found < 0) { found = 0; xover = 1; }               // (cannot happen: the run-level test said the crossing is here)
             xcrow = found;
