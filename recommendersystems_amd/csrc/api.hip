@@ -539,6 +539,21 @@ int32_t rwr_eval_graphs(int32_t count, const rwr_graph_desc *graphs, const int32
         }
         kit.device = o.device;
         rwr::multi_pins_acquire();
+        // Every pinned set starts at sizes the usual batch (tens of ego networks) never outgrows: growing a buffer is a
+        // hipHostFree + hipHostMalloc -- milliseconds each, the first a device synchronisation --, and which set a call
+        // gets changes from call to call, so sets sized by their first batch would keep growing for many calls when ten
+        // threads with batches of different sizes share them.
+        {
+            static const size_t floor_bytes[5] = {(size_t)16 << 20, (size_t)256 << 10, (size_t)256 << 10, (size_t)1 << 20, (size_t)64 << 10};
+            int32_t prc = RWR_OK;
+            void *unused = nullptr;
+            for (int sl = 0; sl < 5 && prc == RWR_OK; ++sl) prc = rwr::multi_pinned(sl, floor_bytes[sl], &unused);
+            if (prc != RWR_OK) {
+                rwr::multi_pins_release();
+                kit_give(kit);
+                return prc;
+            }
+        }
 #ifdef RWR_EXPERIMENTS
         t_kit = now_ms();
 #endif

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import enum
+import itertools
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -86,6 +87,7 @@ class Graph:
                                    tile_seeds, tile_group, 1 if profile else 0, workspace_bytes,
                                    {None: 0, "auto": 0, "fold": 1, "scan": 2, "simple": 3}[seed_row_kernel], 0)
         self._flat = None
+        self._desc = None       # (rwr_graph_desc bytes of _flat: _marshal_graphs)
         self._sent = None
 
     # -- flat constructors (the layout of include/rwr.h), used by the bench for big graphs
@@ -221,6 +223,44 @@ class Graph:
             pass
 
 
+def _desc_raw(flat) -> bytes:
+    node_id, node_type, rowptr, dst, etype, w = flat
+    return bytes(_lib.rwr_graph_desc(int(node_id.shape[0]), 0, _p(node_id, C.c_int64), _p(node_type, C.c_uint8),
+                                     _p(rowptr, C.c_int64), _p(dst, C.c_int32), _p(etype, C.c_uint8), _p(w, C.c_double)))
+
+
+def _marshal_graphs(graphs, testSets):
+    """The arguments of rwr_eval_graphs for a batch: the descriptor array, the test sets as (ptr, ids), and the arrays that
+    must stay alive during the call.  A Graph made from flat arrays keeps its descriptor (its six pointers) with the arrays,
+    so that a batch of such graphs costs the interpreter one bytes.join -- with ten host threads behind one interpreter lock
+    (bench.py --config C1) the per-graph ctypes conversions were most of the call."""
+    K = len(graphs)
+    alive, raw = [], []
+    for g in graphs:
+        if g._flat is not None:
+            if g._desc is None:
+                g._desc = _desc_raw(g._flat)
+            raw.append(g._desc)
+        else:
+            flat = g._flatten()                 # (dictionary graphs: fresh arrays every time, the caller may have changed the lists)
+            alive.append(flat)
+            raw.append(_desc_raw(flat))
+    descs = (_lib.rwr_graph_desc * max(K, 1))()
+    if K:
+        C.memmove(descs, b"".join(raw), K * C.sizeof(_lib.rwr_graph_desc))
+    ptr = np.zeros(K + 1, dtype=np.int64)
+    if K:
+        np.cumsum(np.fromiter(map(len, testSets), dtype=np.int64, count=K), out=ptr[1:])
+    total = int(ptr[K])
+    if total == 0:
+        ids = np.zeros(1, dtype=np.int64)
+    elif all(isinstance(t, np.ndarray) for t in testSets):
+        ids = np.ascontiguousarray(np.concatenate(testSets), dtype=np.int64)
+    else:
+        ids = np.fromiter(itertools.chain.from_iterable(testSets), dtype=np.int64, count=total)
+    return descs, ptr, ids, alive
+
+
 def EvaluateGraphs(graphs, seeds, dampingFactor: float, nIteration: int, testSets, *, device: int = -1):
     """The loop body of the reference's harness (Experiment.cs:69-134) for MANY graphs at once (rwr_eval_graphs):
     graphs[k].buildGraph(); Recommender(graphs[k]).RecommendationEval(seeds[k], d, T, testSets[k]) for every k, with one
@@ -229,16 +269,8 @@ def EvaluateGraphs(graphs, seeds, dampingFactor: float, nIteration: int, testSet
     K = len(graphs)
     if len(seeds) != K or len(testSets) != K:
         raise ValueError("one seed and one test set per graph")
-    flats = [g._flat if g._flat is not None else g._flatten() for g in graphs]
-    descs = (_lib.rwr_graph_desc * max(K, 1))()
-    for k, (node_id, node_type, rowptr, dst, etype, w) in enumerate(flats):
-        descs[k] = _lib.rwr_graph_desc(int(node_id.shape[0]), 0, _p(node_id, C.c_int64), _p(node_type, C.c_uint8),
-                                       _p(rowptr, C.c_int64), _p(dst, C.c_int32), _p(etype, C.c_uint8), _p(w, C.c_double))
+    descs, ptr, ids, _alive = _marshal_graphs(graphs, testSets)
     seeds_a = np.ascontiguousarray(seeds, dtype=np.int32)
-    ptr = np.zeros(K + 1, dtype=np.int64)
-    for k, t in enumerate(testSets):
-        ptr[k + 1] = ptr[k] + len(t)
-    ids = np.ascontiguousarray([x for t in testSets for x in t], dtype=np.int64) if ptr[K] else np.zeros(1, dtype=np.int64)
     hits = np.zeros(K, dtype=np.int64)
     sp = np.zeros(K, dtype=np.float64)
     ln = np.zeros(K, dtype=np.int64)

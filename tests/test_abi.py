@@ -170,3 +170,43 @@ def test_native_thread_tool_builds(tmp_path):
                            os.path.join(ROOT, "tools", "eval_graphs_threads.cpp"), "-o", str(exe), os.path.join(pkg, "librwr.so"),
                            "-Wl,-rpath," + pkg])
     assert exe.exists()
+
+
+def test_batch_marshalling_matches_the_arrays():
+    """EvaluateGraphs' argument marshalling (rwr_based._marshal_graphs): descriptors point at the graphs' own arrays (cached
+    with a flat graph, rebuilt for a dictionary graph), test sets arrive as (ptr, ids) whatever container held them."""
+    from recommendersystems_amd.rwr_based import EdgeType, ForwardLink, Graph, Node, NodeType, _marshal_graphs
+    rng = np.random.default_rng(5)
+    graphs = []
+    for n in (3, 7, 12):
+        deg = rng.integers(0, 4, size=n)
+        rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        m = int(rowptr[-1])
+        graphs.append(Graph.from_flat(np.arange(n) + 100, rng.integers(1, 3, size=n), rowptr, rng.integers(0, n, size=m),
+                                      rng.integers(1, 7, size=m), rng.random(m)))
+    nodes = {0: Node(10, NodeType.USER), 1: Node(11, NodeType.ITEM)}
+    edges = {0: [ForwardLink(1, EdgeType.LIKE, 1.0)], 1: [ForwardLink(0, EdgeType.LIKE, 1.0)]}
+    graphs.append(Graph(nodes, edges))
+    tests = [np.array([5, 3, 5], dtype=np.int64), {9, 1}, [], (4,)]
+    for rep in range(2):                                       # (second time: the cached descriptors)
+        descs, ptr, ids, alive = _marshal_graphs(graphs, tests)
+        assert len(descs) == 4 and len(alive) == 1
+        for k, g in enumerate(graphs):
+            flat = g._flat if g._flat is not None else alive[0]
+            d = descs[k]
+            assert d.n_nodes == flat[0].shape[0] and d.reserved0 == 0
+            got = [C.cast(getattr(d, f), C.c_void_p).value for f in ("node_id", "node_type", "rowptr", "dst", "etype", "w")]
+            assert got == [a.ctypes.data for a in flat]
+        assert ptr.tolist() == [0, 3, 5, 5, 6] and ptr.dtype == np.int64
+        assert ids.dtype == np.int64 and ids.flags.c_contiguous
+        assert ids[:3].tolist() == [5, 3, 5] and sorted(ids[3:5].tolist()) == [1, 9] and ids[5:].tolist() == [4]
+    assert graphs[0]._desc is not None and graphs[3]._desc is None
+    # a dictionary graph is flattened afresh: a change of its lists is seen by the next batch
+    edges[0].append(ForwardLink(1, EdgeType.MENTION, 2.0))
+    descs, _, _, alive = _marshal_graphs(graphs[3:], [[]])
+    assert alive[0][2].tolist() == [0, 2, 3]
+    # no graphs, no test ids: still valid pointers for the C side
+    descs, ptr, ids, _ = _marshal_graphs([], [])
+    assert ptr.tolist() == [0] and ids.shape == (1,)
+    descs, ptr, ids, _ = _marshal_graphs(graphs[:1], [np.zeros(0, dtype=np.int64)])
+    assert ptr.tolist() == [0, 0] and ids.shape == (1,)
