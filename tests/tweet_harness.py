@@ -103,6 +103,12 @@ def make_ego_db(path: str, ego: int = 1000, seed: int = 7, n_friends: int = 55, 
             if t != m:
                 for _ in range(rnd.randint(1, 6)):
                     cur.execute("INSERT INTO mention VALUES(?,?)", (m, t))
+    # (indexes change no query result and no row order -- rows of one key come back in rowid order either way --, only the
+    #  time the restated loader needs: addMentionCount2 asks two COUNT(*) per pair of members, a table scan each without one)
+    for stmt in ("CREATE INDEX follow_s ON follow(source)", "CREATE INDEX tweet_a ON tweet(author)",
+                 "CREATE INDEX retweet_u ON retweet(user)", "CREATE INDEX quote_u ON quote(user)",
+                 "CREATE INDEX favorite_u ON favorite(user)", "CREATE INDEX mention_st ON mention(source, target)"):
+        cur.execute(stmt)
     con.commit()
     con.close()
 
